@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (oracle/_ref/libref.so).
+
+Run in the build container only (needs /root/reference); the .npz files are
+committed, this script is committed, the reference never travels.
+
+    make -C oracle && python oracle/gen_golden.py
+
+What is recorded (SURVEY.md 8(c) list): GEMM known answers (main.c:20-41 and the
+data/a.csv x data/b.csv plumbing case) and random shapes; every lib/matrix.c
+elementwise/reduction op; every lib/conv.c stage, conv()/conv_ddx() as written
+(sentinels document quirk Q1) and in the intended composition; group_norm fwd/bwd;
+relu/softmax; one MNIST-NN SGD step (model/mnist_nn.c:218-315 driven call by call
+through the reference's matrix.h functions).
+
+Big outputs are stored as a digest (sum, abs-sum and a 4096-point strided sample)
+so the fixtures stay small; small ones in full.  All values are fp64, exactly as
+the reference computed them.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REFROOT = "/root/reference"
+L = ref.lib()
+PD = C.POINTER(C.c_double)
+
+
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests", "golden"))
+from inputs import uniform, randint, sample_idx  # noqa: E402  (shared with the tests)
+
+
+def put(d, name, arr, full_limit=16384):
+    """Store arr in full when small, else as a digest."""
+    arr = np.ascontiguousarray(arr, np.float64)
+    if arr.size <= full_limit:
+        d[name] = arr
+    else:
+        flat = arr.ravel()
+        d[name + "__shape"] = np.array(arr.shape, np.int64)
+        d[name + "__sum"] = np.array(flat.sum(dtype=np.float64))
+        d[name + "__asum"] = np.array(np.abs(flat).sum(dtype=np.float64))
+        d[name + "__sample"] = flat[sample_idx(flat.size)]
+
+
+def read_csv(path, n):
+    """The reference's own CSV reader (lib/csv.c:18-57) -> float32[n]."""
+    L.read_csv_contents.restype = C.POINTER(C.c_float)
+    p = L.read_csv_contents(path.encode())
+    out = np.ctypeslib.as_array(p, shape=(n,)).copy()
+    return out
+
+
+# ---- GEMM ---------------------------------------------------------------------
+def gen_gemm():
+    d = {}
+    # main.c:20-41 known answer (printed "1.40 8.50 / 5.00 19.00" by the fp32-typedef build)
+    a = np.array([[1, 2, 3], [4, 5, 6]], np.float64)
+    b = np.array([[1, 0.5], [0.2, 1], [0, 2]], np.float64)
+    d["kat_main_a"], d["kat_main_b"], d["kat_main_c"] = a, b, ref.matmul(a, b)
+    # config 1 plumbing: data/a.csv (3x3) x data/b.csv (6 values as 3x2), read by lib/csv.c
+    a = read_csv(f"{REFROOT}/data/a.csv", 9).astype(np.float64).reshape(3, 3)
+    b = read_csv(f"{REFROOT}/data/b.csv", 6).astype(np.float64).reshape(3, 2)
+    d["csv_a"], d["csv_b"], d["csv_c"] = a, b, ref.matmul(a, b)
+    shapes = [(1, 1, 1), (2, 3, 2), (7, 5, 3), (33, 17, 65), (65, 129, 33), (129, 65, 257), (257, 33, 129),
+              (128, 128, 128), (64, 256, 64), (10, 128, 64), (1, 512, 128), (300, 1, 40)]
+    d["shapes"] = np.array(shapes, np.int64)
+    for i, (m, k, n) in enumerate(shapes):
+        a = uniform(100 + i, (m, k)); b = uniform(200 + i, (k, n))
+        c = ref.matmul_inplace(a, b)
+        assert np.array_equal(c, ref.matmul(a, b))
+        d[f"rand{i}_c"] = c  # inputs are regenerated from the seed by tests (tests/golden/inputs.py)
+    np.savez_compressed(os.path.join(GOLD, "gemm.npz"), **d)
+
+
+# ---- lib/matrix.c ops ------------------------------------------------------------
+def gen_matrix_ops():
+    d = {}
+    shapes = [(3, 5), (16, 16), (37, 64), (64, 37)]
+    d["shapes"] = np.array(shapes, np.int64)
+    for i, (r, c) in enumerate(shapes):
+        a = uniform(300 + i, (r, c), -2, 2); b = uniform(400 + i, (r, c), -2, 2)
+        d[f"s{i}_scale"] = ref.inplace1("matrix_scale", a, C.c_double(-0.37))
+        d[f"s{i}_add"] = ref.inplace2("matrix_add", a, b)
+        d[f"s{i}_hadamard"] = ref.inplace2("matrix_multiply_elementwise", a, b)
+        d[f"s{i}_transpose"] = ref.inplace1("matrix_transpose", a)
+        d[f"s{i}_row_sum"] = ref.take(L.matrix_row_sum(ref.mat(a)))
+        if r <= c:  # defined behaviour only (Q2); rows > cols is a heap over-read in the reference
+            d[f"s{i}_col_sum"] = ref.take(L.matrix_col_sum(ref.mat(a)))
+        d[f"s{i}_frobenius"] = np.array(L.frobenius_norm(ref.mat(a)))
+        d[f"s{i}_max"] = np.array(L.max_value(ref.mat(a)))
+        d[f"s{i}_zscore"] = ref.inplace1("matrix_z_score_normalize", a)
+        bias_c = uniform(500 + i, (r, 1)); bias_r = uniform(600 + i, (1, c))
+        d[f"s{i}_tile_cols"] = ref.inplace2("matrix_add_tile_columns", a, bias_c)
+        d[f"s{i}_tile_rows"] = ref.inplace2("matrix_add_tile_rows", a, bias_r)
+        # tiling a wider b (i % b.cols), lib/matrix.c:192
+        if c % 2 == 0:
+            d[f"s{i}_tile_cols2"] = ref.inplace2("matrix_add_tile_columns", a, uniform(700 + i, (r, 2)))
+        d[f"s{i}_relu"] = ref.data_fn("relu", a, a.size)
+        d[f"s{i}_softmax_cols"] = ref.data_fn("softmax", a * 4, r, c)
+        d[f"s{i}_softmax_rows"] = ref.data_fn("softmax_row_wise", a * 4, r, c)
+    # the SURVEY's documented example: [1 2 3; 4 5 6] -> 6, 12 (true 6, 15)
+    ex = np.array([[1, 2, 3], [4, 5, 6]], np.float64)
+    d["colsum_example"] = ref.take(L.matrix_col_sum(ref.mat(ex)))
+    np.savez_compressed(os.path.join(GOLD, "matrix_ops.npz"), **d)
+
+
+# ---- lib/conv.c -----------------------------------------------------------------
+def run_conv_stages(d, tag, h, w, cin, cout, k, s, seed, full_limit=16384):
+    ho = int(np.ceil(np.float32(h) / s)); wo = int(np.ceil(np.float32(w) / s))
+    x = uniform(seed, (cin, h, w), -1, 1)
+    kern = uniform(seed + 1, (cout, cin, k, k), -0.3, 0.3)
+    xm = ref.mats(x); kp, _keep = ref.kernel_ptrs(kern)
+    im = np.zeros((ho * wo, k * k * cin)); imm = ref.mat(im)
+    L._im2col(xm, C.byref(imm), k, cin, s)
+    km = np.zeros((k * k * cin, cout)); kmm = ref.mat(km)
+    L._reshape_kernels_matrix(kp, C.byref(kmm))
+    prod = ref.matmul_inplace(im, km)
+    # intended final step: as written reshape_channels_matrix(channels, matrix) does channels <- matrix (Q1)
+    out = np.zeros((cout, ho, wo)); om = ref.mats(out); pm = ref.mat(prod)
+    L.reshape_channels_matrix(om, C.byref(pm))
+    back = np.zeros_like(prod); bm = ref.mat(back)
+    L.reshape_matrix_channels(C.byref(bm), om)
+    assert np.array_equal(back, prod)
+    k2 = np.zeros_like(kern); k2p, _keep2 = ref.kernel_ptrs(k2)
+    L._reshape_matrix_kernels(C.byref(kmm), k2p)
+    assert np.array_equal(k2, kern)
+    put(d, f"{tag}_im2col", im, full_limit); put(d, f"{tag}_kmat", km, full_limit)
+    put(d, f"{tag}_product", prod, full_limit); put(d, f"{tag}_output", out, full_limit)
+    if s == 1:
+        # col2im on a fresh random column matrix, and the intended conv_ddx chain
+        cols = uniform(seed + 2, (h * w, k * k * cin), -1, 1)
+        dx = np.zeros((cin, h, w)); dxm = ref.mats(dx); cm = ref.mat(cols)
+        L._col2im(C.byref(cm), dxm, k, cin, 1)
+        put(d, f"{tag}_col2im", dx, full_limit)
+        del_y = uniform(seed + 3, (cout, h, w), -1, 1)
+        dq = np.zeros((h * w, cout)); dqm = ref.mat(dq)
+        L.reshape_matrix_channels(C.byref(dqm), ref.mats(del_y))          # del_Q <- del_Y (intended direction)
+        imt = ref.inplace1("matrix_transpose", im)
+        dkm = ref.matmul_inplace(imt, dq)                                 # conv.c:221-222
+        dkern = np.zeros_like(kern); dkp, _k3 = ref.kernel_ptrs(dkern); dkmm = ref.mat(dkm)
+        L._reshape_matrix_kernels(C.byref(dkmm), dkp)                     # :223
+        kmt = ref.inplace1("matrix_transpose", km)
+        dcol = ref.matmul_inplace(dq, kmt)                                # :225-226
+        dxi = np.zeros((cin, h, w)); dcm = ref.mat(dcol)
+        L._col2im(C.byref(dcm), ref.mats(dxi), k, cin, 1)                 # :228
+        put(d, f"{tag}_ddx_del_q", dq, full_limit); put(d, f"{tag}_ddx_del_kmat", dkm, full_limit)
+        put(d, f"{tag}_ddx_del_kern", dkern, full_limit); put(d, f"{tag}_ddx_del_col", dcol, full_limit)
+        put(d, f"{tag}_ddx_del_x", dxi, full_limit)
+    return x, kern, im, km, prod
+
+
+def gen_conv():
+    d = {}
+    cfgs = [(8, 8, 3, 4, 3, 1), (8, 8, 3, 4, 3, 2), (7, 9, 2, 3, 3, 2), (6, 6, 2, 5, 1, 1), (32, 32, 3, 8, 3, 2),
+            (5, 7, 3, 2, 3, 1), (32, 32, 128, 128, 3, 1)]
+    d["cfgs"] = np.array(cfgs, np.int64)
+    for i, (h, w, cin, cout, k, s) in enumerate(cfgs):
+        run_conv_stages(d, f"c{i}", h, w, cin, cout, k, s, 1000 + 10 * i)
+    # conv()/conv_ddx() AS WRITTEN with sentinels (documents Q1): cfg 0
+    h, w, cin, cout, k, s = cfgs[0]
+    x = uniform(1000, (cin, h, w), -1, 1); kern = uniform(1001, (cout, cin, k, k), -0.3, 0.3)
+    im = np.zeros((h * w, k * k * cin)); km = np.zeros((k * k * cin, cout)); prod = np.zeros((h * w, cout))
+    out = np.full((cout, h, w), -777.0)
+    imm, kmm, pm = ref.mat(im), ref.mat(km), ref.mat(prod)
+    om = ref.mats(out)
+
+    class ConvData(C.Structure):
+        _fields_ = [("im2col", ref.PM), ("kernel_matrix", ref.PM), ("product", ref.PM), ("output", ref.PM)]
+    cd = ConvData(C.pointer(imm), C.pointer(kmm), C.pointer(pm), C.cast(om, ref.PM))
+    kp, _keep = ref.kernel_ptrs(kern)
+    L.conv(ref.mats(x), kp, C.byref(cd), cin, cout, s)
+    d["aswritten_conv_product"] = prod.copy()      # == -777 everywhere: product <- stale output
+    d["aswritten_conv_output"] = out.copy()        # == -777 everywhere: never written
+    # conv_ddx as written: del_Y is overwritten from the stale del_Q, gradients come from the stale del_Q
+    del_y = uniform(1003, (cout, h, w), -1, 1)
+    g_im = np.zeros_like(im); g_km = np.zeros_like(km); g_prod = uniform(1004, (h * w, cout), -1, 1)
+    g_prod0 = g_prod.copy()
+    gimm, gkmm, gpm = ref.mat(g_im), ref.mat(g_km), ref.mat(g_prod)
+    gcd = ConvData(C.pointer(gimm), C.pointer(gkmm), C.pointer(gpm), None)
+    # restore forward workspaces (im2col/kernel_matrix are valid; they were computed before the last step)
+    dkern = np.zeros_like(kern); dkp, _k2 = ref.kernel_ptrs(dkern)
+    dx = np.zeros((cin, h, w))
+    L.conv_ddx(ref.mats(del_y), C.byref(cd), C.byref(gcd), dkp, ref.mats(dx), cin, 1)
+    d["aswritten_ddx_stale_del_q"] = g_prod0
+    d["aswritten_ddx_del_y_after"] = del_y.copy()
+    d["aswritten_ddx_del_kern"] = dkern
+    d["aswritten_ddx_del_x"] = dx
+    np.savez_compressed(os.path.join(GOLD, "conv.npz"), **d)
+
+
+# ---- lib/norm.c -------------------------------------------------------------------
+def gen_norm():
+    d = {}
+    cfgs = [(3, 32, 8, 8), (128, 32, 8, 8), (40, 32, 4, 6), (64, 16, 2, 2)]
+    d["cfgs"] = np.array(cfgs, np.int64)
+    L.group_norm.argtypes = [ref.PM, ref.PM, PD, PD, C.c_int, C.c_int]
+    L.group_norm_ddx.argtypes = [ref.PM, ref.PM, ref.PM, PD, PD, C.c_int, C.c_int]
+    for i, (c, g, h, w) in enumerate(cfgs):
+        x = uniform(2000 + i, (c, h, w), -1, 3)
+        ng = (c + g - 1) // g
+        out = np.zeros_like(x); sd = np.zeros(ng); mu = np.zeros(ng)
+        L.group_norm(C.cast(ref.mats(x), ref.PM), C.cast(ref.mats(out), ref.PM),
+                     sd.ctypes.data_as(PD), mu.ctypes.data_as(PD), c, g)
+        up = uniform(2100 + i, (c, h, w), -1, 1)
+        dest = np.zeros_like(x)
+        L.group_norm_ddx(C.cast(ref.mats(up), ref.PM), C.cast(ref.mats(dest), ref.PM), C.cast(ref.mats(x), ref.PM),
+                         mu.ctypes.data_as(PD), sd.ctypes.data_as(PD), c, g)
+        d[f"n{i}_out"], d[f"n{i}_stdevs"], d[f"n{i}_means"], d[f"n{i}_ddx"] = out, sd, mu, dest
+    # documented probe: group {1..8} -> mean 4.5, "stdev" 5.25, out[0] = -0.6667
+    x = np.arange(1, 9, dtype=np.float64).reshape(2, 2, 2)
+    out = np.zeros_like(x); sd = np.zeros(1); mu = np.zeros(1)
+    L.group_norm(C.cast(ref.mats(x), ref.PM), C.cast(ref.mats(out), ref.PM), sd.ctypes.data_as(PD), mu.ctypes.data_as(PD), 2, 32)
+    d["probe_out"], d["probe_sd"], d["probe_mu"] = out, sd, mu
+    np.savez_compressed(os.path.join(GOLD, "norm.npz"), **d)
+
+
+# ---- model/mnist_nn.c:218-315 driven through the reference's matrix.h ---------------
+def ref_mnist_step(params, x_raw, y, intended_colsum):
+    w1, b1, w2, b2, w3, b3 = [np.ascontiguousarray(p, np.float64).copy() for p in params]
+    B = x_raw.shape[1]
+    n0 = w1.shape[1]
+    x = ref.inplace1("matrix_scale", x_raw, C.c_double(np.float32(1) / np.float32(255.0)))   # :218 (1/255.0F)
+
+    def fwd(w, a, b):
+        z = ref.matmul(w, a)                                    # matrix_multiply
+        z = ref.inplace2("matrix_add_tile_columns", z, b)
+        return z
+
+    def colsum(m):
+        if intended_colsum:   # true row sums via the reference's own row_sum of the transpose
+            mt = np.ascontiguousarray(ref.inplace1("matrix_transpose", m))   # keep alive across the call
+            return ref.take(L.matrix_row_sum(ref.mat(mt))).reshape(-1, 1)
+        assert m.shape[0] <= m.shape[1]
+        mc = np.ascontiguousarray(m)
+        return ref.take(L.matrix_col_sum(ref.mat(mc)))
+
+    z1 = fwd(w1, x, b1); a1 = ref.data_fn("relu", z1, z1.size)
+    z2 = fwd(w2, a1, b2); a2 = ref.data_fn("relu", z2, z2.size)
+    z3 = fwd(w3, a2, b3); a3 = ref.data_fn("softmax", z3, z3.shape[0], B)
+    scale = 1 / float(n0)                                        # :260
+    ny = ref.inplace1("matrix_scale", y, C.c_double(-1.0))
+    dz3 = ref.inplace2("matrix_add", a3, ny)
+    dz3 = ref.inplace1("matrix_scale", dz3, C.c_double(scale))
+    dw3 = ref.matmul(dz3, ref.inplace1("matrix_transpose", a2)); db3 = colsum(dz3)
+    da2 = ref.matmul(ref.inplace1("matrix_transpose", w3), dz3)
+    dz2 = ref.inplace2("matrix_multiply_elementwise", (z2 > 0).astype(np.float64), da2)
+    dw2 = ref.matmul(dz2, ref.inplace1("matrix_transpose", a1)); db2 = colsum(dz2)
+    da1 = ref.matmul(ref.inplace1("matrix_transpose", w2), dz2)
+    dz1 = ref.inplace2("matrix_multiply_elementwise", (z1 > 0).astype(np.float64), da1)
+    dw1 = ref.matmul(dz1, ref.inplace1("matrix_transpose", x)); db1 = colsum(dz1)
+    grads = [dw1, db1, dw2, db2, dw3, db3]
+    lr = float(np.float32(-0.02))                                # float epoch_learn_rate, :186
+    new = []
+    for p, g in zip([w1, b1, w2, b2, w3, b3], grads):
+        new.append(ref.inplace2("matrix_add", p, ref.inplace1("matrix_scale", g, C.c_double(lr))))
+    return new, dict(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, a3=a3), grads
+
+
+def load_mnist_params():
+    shapes = [(256, 784), (256, 1), (128, 256), (128, 1), (10, 128), (10, 1)]
+    files = ["weights_1", "biases_1", "weights_2", "biases_2", "weights_3", "biases_3"]
+    return [read_csv(f"{REFROOT}/data/mnist_nn/{f}.csv", r * c).reshape(r, c) for f, (r, c) in zip(files, shapes)]
+
+
+def gen_mnist():
+    params32 = load_mnist_params()   # trained reference weights (fp32 as lib/csv.c returns them)
+    np.savez_compressed(os.path.join(GOLD, "mnist_nn_params.npz"),
+                        **{n: p for n, p in zip(["w1", "b1", "w2", "b2", "w3", "b3"], params32)})
+    d = {}
+    params = [p.astype(np.float64) for p in params32]
+    for tag, B, intended in [("b256_aswritten", 256, False), ("b64_intended", 64, True), ("b256_intended", 256, True)]:
+        x_raw = randint(3000 + B, (784, B), 256).astype(np.float64)
+        lab = randint(3100 + B, (B,), 10)
+        y = np.zeros((10, B)); y[lab, np.arange(B)] = 1
+        new, acts, grads = ref_mnist_step(params, x_raw, y, intended)
+        for n, v in zip(["w1", "b1", "w2", "b2", "w3", "b3"], new):
+            put(d, f"{tag}_new_{n}", v, 4096)
+        for n, v in zip(["dw1", "db1", "dw2", "db2", "dw3", "db3"], grads):
+            put(d, f"{tag}_{n}", v, 4096)
+        for n, v in acts.items():
+            put(d, f"{tag}_{n}", v, 4096)
+    # tiny architecture stored in full: 12 -> 8 -> 6 -> 4, B = 16 (all col_sum windows in bounds)
+    sizes = (12, 8, 6, 4); B = 16
+    tp = [uniform(3200, (8, 12)), uniform(3201, (8, 1)), uniform(3202, (6, 8)), uniform(3203, (6, 1)),
+          uniform(3204, (4, 6)), uniform(3205, (4, 1))]
+    x_raw = randint(3206, (12, B), 256).astype(np.float64)
+    lab = randint(3207, (B,), 4); y = np.zeros((4, B)); y[lab, np.arange(B)] = 1
+    for tag, intended in [("tiny_aswritten", False), ("tiny_intended", True)]:
+        new, acts, grads = ref_mnist_step(tp, x_raw, y, intended)
+        for n, v in zip(["w1", "b1", "w2", "b2", "w3", "b3"], new):
+            d[f"{tag}_new_{n}"] = v
+        for n, v in zip(["dw1", "db1", "dw2", "db2", "dw3", "db3"], grads):
+            d[f"{tag}_{n}"] = v
+        for n, v in acts.items():
+            d[f"{tag}_{n}"] = v
+    np.savez_compressed(os.path.join(GOLD, "mnist_step.npz"), **d)
+
+
+if __name__ == "__main__":
+    assert ref.available(), "build oracle/_ref first: make -C oracle"
+    os.makedirs(GOLD, exist_ok=True)
+    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist()
+    tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print("golden vectors written to", GOLD, f"({tot/1e6:.2f} MB)")

@@ -1,0 +1,329 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, bench.py's cpu_baseline leg
+and __graft_entry__.smoke(); never from the product package.
+
+Every function mirrors one reference function (file:line in oracle_impl.inc) on
+flat row-major numpy arrays.  dtype float64 selects the ora64_* instantiation
+(the reference's own matrix_float_t, lib/matrix.h:4), float32 the ora32_* one.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile liboracle*.so (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_impl.inc", "Makefile")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so", "liboracle_O0.so"])
+    if os.path.isdir("/root/reference/lib"):
+        ref = os.path.join(_HERE, "_ref", "libref.so")
+        if force or not os.path.exists(ref):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib(opt="O2"):
+    name = "liboracle.so" if opt == "O2" else "liboracle_O0.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        _LIBS[name] = C.CDLL(path)
+    return _LIBS[name]
+
+
+def _pfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "ora64_", C.c_double
+    if dtype == np.float32:
+        return "ora32_", C.c_float
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype=None):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _call(name, dtype, *args, restype=None, opt="O2"):
+    pfx, _ = _pfx(dtype)
+    fn = getattr(lib(opt), pfx + name)
+    fn.restype = restype
+    return fn(*args)
+
+
+# ---- lib/matrix.c ---------------------------------------------------------
+def matmul(a, b, opt="O2"):
+    a, b = _c(a), _c(b)
+    assert a.dtype == b.dtype and a.shape[1] == b.shape[0]
+    c = np.empty((a.shape[0], b.shape[1]), a.dtype)
+    _call("matmul", a.dtype, _p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1], opt=opt)
+    return c
+
+
+def matmul_rows(a, b, c, row0, row1, opt="O2"):
+    _call("matmul_rows", a.dtype, _p(a), _p(b), _p(c), a.shape[1], b.shape[1], row0, row1, opt=opt)
+
+
+def scale(m, f):
+    m = _c(m).copy()
+    _, ct = _pfx(m.dtype)
+    _call("scale", m.dtype, _p(m), m.size, ct(f))
+    return m
+
+
+def add(a, b):
+    a = _c(a).copy(); b = _c(b, a.dtype)
+    _call("add", a.dtype, _p(a), _p(b), a.size)
+    return a
+
+
+def hadamard(a, b):
+    a = _c(a).copy(); b = _c(b, a.dtype)
+    _call("hadamard", a.dtype, _p(a), _p(b), a.size)
+    return a
+
+
+def transpose(m):
+    m = _c(m)
+    out = np.empty((m.shape[1], m.shape[0]), m.dtype)
+    _call("transpose", m.dtype, _p(m), _p(out), m.shape[0], m.shape[1])
+    return out
+
+
+def row_sum(m):
+    m = _c(m)
+    out = np.empty((1, m.shape[1]), m.dtype)
+    _call("row_sum", m.dtype, _p(m), _p(out), m.shape[0], m.shape[1])
+    return out
+
+
+def col_sum_as_written(m):
+    """lib/matrix.c:138-148 literally; None where the reference reads out of bounds."""
+    m = _c(m)
+    out = np.empty((m.shape[0], 1), m.dtype)
+    ok = _call("col_sum_as_written", m.dtype, _p(m), _p(out), m.shape[0], m.shape[1], restype=C.c_int)
+    return out if ok else None
+
+
+def col_sum_intended(m):
+    m = _c(m)
+    out = np.empty((m.shape[0], 1), m.dtype)
+    _call("col_sum_intended", m.dtype, _p(m), _p(out), m.shape[0], m.shape[1])
+    return out
+
+
+def frobenius(m):
+    m = _c(m)
+    _, ct = _pfx(m.dtype)
+    return _call("frobenius", m.dtype, _p(m), m.shape[0], m.shape[1], restype=ct)
+
+
+def max_value(m):
+    m = _c(m)
+    _, ct = _pfx(m.dtype)
+    return _call("max_value", m.dtype, _p(m), m.size, restype=ct)
+
+
+def zscore(m):
+    m = _c(m).copy()
+    _call("zscore", m.dtype, _p(m), m.size)
+    return m
+
+
+def add_tile_columns(a, b):
+    a = _c(a).copy(); b = _c(b, a.dtype)
+    _call("add_tile_columns", a.dtype, _p(a), _p(b), a.shape[0], a.shape[1], b.shape[1])
+    return a
+
+
+def add_tile_rows(a, b):
+    a = _c(a).copy(); b = _c(b, a.dtype)
+    _call("add_tile_rows", a.dtype, _p(a), _p(b), a.shape[0], a.shape[1])
+    return a
+
+
+# ---- lib/util.c / model/mnist_nn.c ------------------------------------------
+def relu(d):
+    d = _c(d).copy()
+    _call("relu", d.dtype, _p(d), d.size)
+    return d
+
+
+def relu_ddx(d):
+    d = _c(d).copy()
+    _call("relu_ddx", d.dtype, _p(d), d.size)
+    return d
+
+
+def softmax_cols(d):
+    d = _c(d).copy()
+    _call("softmax_cols", d.dtype, _p(d), d.shape[0], d.shape[1])
+    return d
+
+
+def softmax_rows(d):
+    d = _c(d).copy()
+    _call("softmax_rows", d.dtype, _p(d), d.shape[0], d.shape[1])
+    return d
+
+
+# ---- lib/conv.c -------------------------------------------------------------
+def out_hw(h, w, s):
+    """ceil((float)H/s) as lib/conv.c:55-56."""
+    return int(np.ceil(np.float32(h) / s)), int(np.ceil(np.float32(w) / s))
+
+
+def im2col(x, k, s):
+    x = _c(x); c, h, w = x.shape
+    ho, wo = out_hw(h, w, s)
+    out = np.empty((ho * wo, k * k * c), x.dtype)
+    _call("im2col", x.dtype, _p(x), _p(out), h, w, k, c, s)
+    return out
+
+
+def col2im(cols, c, h, w, k, s=1):
+    cols = _c(cols)
+    out = np.empty((c, h, w), cols.dtype)
+    ok = _call("col2im", cols.dtype, _p(cols), _p(out), h, w, k, c, s, restype=C.c_int)
+    return out if ok else None
+
+
+def kernels_to_matrix(kern):
+    kern = _c(kern); f, c, k, _ = kern.shape
+    mat = np.empty((k * k * c, f), kern.dtype)
+    _call("kernels_to_matrix", kern.dtype, _p(kern), _p(mat), f, c, k)
+    return mat
+
+
+def matrix_to_kernels(mat, c, k):
+    mat = _c(mat); f = mat.shape[1]
+    kern = np.empty((f, c, k, k), mat.dtype)
+    _call("matrix_to_kernels", mat.dtype, _p(mat), _p(kern), f, c, k)
+    return kern
+
+
+def reshape_channels_matrix(matrix, h, w):
+    """AS WRITTEN (lib/conv.c:174-187): matrix [HW][C] -> channels [C][H][W]."""
+    matrix = _c(matrix); c = matrix.shape[1]
+    ch = np.empty((c, h, w), matrix.dtype)
+    _call("reshape_channels_matrix", matrix.dtype, _p(ch), _p(matrix), c, h * w)
+    return ch
+
+
+def reshape_matrix_channels(channels):
+    """AS WRITTEN (lib/conv.c:190-203): channels [C][H][W] -> matrix [HW][C]."""
+    channels = _c(channels); c, h, w = channels.shape
+    m = np.empty((h * w, c), channels.dtype)
+    _call("reshape_matrix_channels", channels.dtype, _p(m), _p(channels), c, h * w)
+    return m
+
+
+def conv_intended(x, kern, s):
+    x, kern = _c(x), _c(kern)
+    c, h, w = x.shape; f, _, k, _ = kern.shape
+    ho, wo = out_hw(h, w, s)
+    ws = dict(im2col=np.empty((ho * wo, k * k * c), x.dtype), kmat=np.empty((k * k * c, f), x.dtype),
+              product=np.empty((ho * wo, f), x.dtype), output=np.empty((f, ho, wo), x.dtype))
+    _call("conv_intended", x.dtype, _p(x), _p(kern), _p(ws["im2col"]), _p(ws["kmat"]), _p(ws["product"]),
+          _p(ws["output"]), h, w, k, c, f, s)
+    return ws
+
+
+def conv_as_written(x, kern, s, stale_output):
+    x, kern, stale_output = _c(x), _c(kern), _c(stale_output)
+    c, h, w = x.shape; f, _, k, _ = kern.shape
+    ho, wo = out_hw(h, w, s)
+    ws = dict(im2col=np.empty((ho * wo, k * k * c), x.dtype), kmat=np.empty((k * k * c, f), x.dtype),
+              product=np.empty((ho * wo, f), x.dtype), output=stale_output)
+    _call("conv_as_written", x.dtype, _p(x), _p(kern), _p(ws["im2col"]), _p(ws["kmat"]), _p(ws["product"]),
+          _p(stale_output), h, w, k, c, f, s)
+    return ws
+
+
+def conv_ddx_intended(del_y, im2col_m, kmat, c_in, k, s=1):
+    del_y, im2col_m, kmat = _c(del_y), _c(im2col_m), _c(kmat)
+    f, h, w = del_y.shape
+    dt = del_y.dtype
+    out = dict(del_q=np.empty((h * w, f), dt), del_kmat=np.empty((k * k * c_in, f), dt),
+               del_kern=np.empty((f, c_in, k, k), dt), del_col=np.empty((h * w, k * k * c_in), dt),
+               del_x=np.empty((c_in, h, w), dt))
+    ok = _call("conv_ddx_intended", dt, _p(del_y), _p(im2col_m), _p(kmat), _p(out["del_q"]), _p(out["del_kmat"]),
+               _p(out["del_kern"]), _p(out["del_col"]), _p(out["del_x"]), h, w, k, c_in, f, s, restype=C.c_int)
+    return out if ok else None
+
+
+# ---- lib/norm.c -------------------------------------------------------------
+def group_norm(x, group_size):
+    x = _c(x); c, h, w = x.shape
+    ng = (c + group_size - 1) // group_size
+    out = np.empty_like(x); sd = np.empty(ng, x.dtype); mu = np.empty(ng, x.dtype)
+    _call("group_norm", x.dtype, _p(x), _p(out), _p(sd), _p(mu), c, group_size, h * w)
+    return out, sd, mu
+
+
+def group_norm_ddx(source, data, means, stdevs, group_size):
+    source = _c(source); data = _c(data, source.dtype)
+    means = _c(means, source.dtype); stdevs = _c(stdevs, source.dtype)
+    c, h, w = source.shape
+    dest = np.empty_like(source)
+    _call("group_norm_ddx", source.dtype, _p(source), _p(dest), _p(data), _p(means), _p(stdevs), c, group_size, h * w)
+    return dest
+
+
+# ---- model/mnist_nn.c:218-315 -------------------------------------------------
+def bucket_sizes(sizes):
+    n0, n1, n2, n3 = sizes
+    return [n1 * n0, n1, n2 * n1, n2, n3 * n2, n3]
+
+
+def mnist_step(params, x_raw, y, colsum_intended=False):
+    """One SGD step.  params = [w1,b1,w2,b2,w3,b3] (updated copies are returned).
+    Returns (new_params, acts dict, grads list) or None where the as-written
+    col_sum would be out of bounds."""
+    dt = np.dtype(params[0].dtype)
+    ps = [_c(p, dt).copy() for p in params]
+    x_raw, y = _c(x_raw, dt), _c(y, dt)
+    n1, n0 = ps[0].shape; n2 = ps[2].shape[0]; n3 = ps[4].shape[0]; B = x_raw.shape[1]
+    acts = np.empty(2 * (n1 + n2 + n3) * B, dt)
+    grads = np.empty(sum(bucket_sizes((n0, n1, n2, n3))), dt)
+    ok = _call("mnist_step", dt, *[_p(p) for p in ps], _p(x_raw), _p(y), n0, n1, n2, n3, B,
+               int(colsum_intended), _p(acts), _p(grads), restype=C.c_int)
+    if not ok:
+        return None
+    names = ["z1", "a1", "z2", "a2", "z3", "a3"]
+    rows = [n1, n1, n2, n2, n3, n3]
+    ad, off = {}, 0
+    for nm, r in zip(names, rows):
+        ad[nm] = acts[off:off + r * B].reshape(r, B); off += r * B
+    gl, off = [], 0
+    for sz, p in zip(bucket_sizes((n0, n1, n2, n3)), ps):
+        gl.append(grads[off:off + sz].reshape(p.shape)); off += sz
+    return ps, ad, gl
+
+
+# ---- error-bound helpers ------------------------------------------------------
+def matmul_f32_acc64(a, b):
+    a, b = _c(a, np.float32), _c(b, np.float32)
+    c = np.empty((a.shape[0], b.shape[1]), np.float64)
+    lib().ora_matmul_f32_acc64(_p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1])
+    return c
+
+
+def matmul_abs_f32(a, b):
+    a, b = _c(a, np.float32), _c(b, np.float32)
+    c = np.empty((a.shape[0], b.shape[1]), np.float64)
+    lib().ora_matmul_abs_f32(_p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1])
+    return c

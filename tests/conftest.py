@@ -1,0 +1,44 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pkg():
+    """Import big-linear-algebra_amd/ (the directory name is not a Python identifier)."""
+    name = "big_linear_algebra_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "big-linear-algebra_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def ora():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+def golden(name):
+    from inputs import Golden
+    return Golden(os.path.join(ROOT, "tests", "golden", name + ".npz"))
