@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Primary workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+square fp32 matrix_multiply, N = 4096, both operands and the output resident in HBM, one
+"step" = one C = A @ B through the C-ABI (bla_gemm_f32).  With N > 1 ranks every rank runs
+its own replica (a square GEMM has no exchange step: "replicas only") and the
+value is the aggregate over ranks.
+
+Rank 0 prints ONE JSON line carrying, besides the contract keys, `roofline` (dominant kernel vs the
+gfx950 fp32 MFMA peak, timed with HIP events on the launch stream) and `cpu_baseline` (the reference's
+own loop, lib/matrix.c:47-57, timed on this host on a bounded slice of the same product).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+
+
+def cpu_baseline_gemm(n, target_seconds=12.0):
+    """Times the reference's i-j-k loop on a row slice of the same n x n product, 1 core.
+    Uses the reference itself (oracle/_ref/libref.so, kind "reference") when that build is
+    present, else this repo's restatement (kind "port")."""
+    from inputs import uniform
+    import oracle
+    import ref
+    a = uniform(0xB1A5, (n, n)); b = uniform(0xB1A6, (n, n))          # fp64, the reference's element type
+    est_gflops = 0.4
+    rows = int(max(8, min(n, target_seconds * est_gflops * 1e9 / (2.0 * n * n))))
+    rows = (rows // 8) * 8
+    a_slice = np.ascontiguousarray(a[:rows])
+    if ref.available():
+        kind = "reference"
+        t0 = time.perf_counter()
+        c = ref.matmul_inplace(a_slice, b)                             # matrix_multiply_inplace, lib/matrix.c:47-57
+        dt = time.perf_counter() - t0
+    else:
+        kind = "port"
+        oracle.build()
+        c = np.zeros((rows, n))
+        t0 = time.perf_counter()
+        oracle.matmul_rows(a_slice, b, c, 0, rows)
+        dt = time.perf_counter() - t0
+    gflops = 2.0 * rows * n * n / dt / 1e9
+    return {"value": round(gflops, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind, "dtype": "f64",
+            "sample": f"{rows} of {n} output rows of the same {n}^3 product, gcc -O2, {dt:.1f} s",
+            "full_product_seconds_extrapolated": round(2.0 * n ** 3 / (gflops * 1e9), 1)}, c, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=4096, help="square GEMM size (BASELINE configs[1]: 1024..8192)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from __graft_entry__ import load_pkg
+    bla = load_pkg()
+    bla.init(local_rank)
+    L = bla.lib()
+    from inputs import uniform
+
+    n = args.size
+    a = uniform(0xB1A5, (n, n), dtype=np.float32)
+    b = uniform(0xB1A6, (n, n), dtype=np.float32)
+    da, db, dc = bla.to_device(a), bla.to_device(b), bla.empty((n, n))
+    stream = L.bla_default_stream()
+
+    def step():
+        bla.gemm(da, db, dc, stream=stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        bla.sync(stream)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    bla.native.check(L.bla_event_create(C.byref(ev0)))
+    bla.native.check(L.bla_event_create(C.byref(ev1)))
+    barrier()
+    t0 = time.perf_counter()
+    bla.native.check(L.bla_event_record(ev0, stream))
+    for _ in range(args.steps):
+        step()
+    bla.native.check(L.bla_event_record(ev1, stream))
+    barrier()
+    wall = time.perf_counter() - t0
+    ms = C.c_float()
+    bla.native.check(L.bla_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+    kernel_ms = ms.value / args.steps                       # HIP events on the launch stream: per-launch duration
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    flops = 2.0 * n ** 3
+    value = world * args.steps * flops / wall / 1e9          # whole-job GFLOP/s over the barrier-bracketed region
+    achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "fp32 GFLOP/s matrix_mul 4096^3" if n == 4096 else f"fp32 GFLOP/s matrix_mul {n}^3",
+        "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"square fp32 matrix_multiply N={n} (BASELINE configs[1]), operands resident in HBM",
+                   "kernel": L.bla_gemm_last_kernel().decode(), "parallelism": f"replicas x{world}"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": 3 * n * n * 4},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, c_cpu, rows = cpu_baseline_gemm(n)
+        out["cpu_baseline"] = base
+        # the same slice doubles as a correctness check of what was just timed
+        got = dc.numpy()[:rows].astype(np.float64)
+        err = np.linalg.norm(got - c_cpu) / np.linalg.norm(c_cpu)
+        out["config"]["rel_err_vs_cpu_slice"] = float(f"{err:.3e}")
+        assert err < 1e-5, f"GPU result differs from the CPU reference slice: {err}"
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

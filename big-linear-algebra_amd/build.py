@@ -1,0 +1,99 @@
+"""In-tree native build of the package (no pip, no JIT cache):
+
+    csrc/*.hip      --hipcc --offload-arch=gfx950-->  csrc/libbla_hip.so   (HIP kernels + C-ABI, include/bla.h)
+    lib/*.c         --gcc-->                          lib/libbla_host.so   (drop-in matrix.h/conv.h/... host API)
+
+The HIP runtime we link against is the one PyTorch-ROCm ships (torch/lib/libamdhip64.so, SONAME
+libamdhip64.so) so that a process that also imports torch (bench.py: torch.distributed over RCCL)
+holds exactly ONE HIP runtime and torch's stream handles are valid in our launches.
+hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU-only build container.
+"""
+import glob
+import importlib.util
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "lib")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+HIP_SO = os.path.join(CSRC, "libbla_hip.so")
+HOST_SO = os.path.join(HOST, "libbla_host.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def torch_lib_dir():
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError(f"native build failed: {cmd[0]} exited {r.returncode}")
+    return r.stdout
+
+
+def build_hip(force=False, verbose=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    objs = []
+    jobs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                   "-DBLA_BUILDING", "-I", INCLUDE, "-c", s, "-o", o]
+            jobs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
+    for s, p, cmd in jobs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
+            raise RuntimeError(f"hipcc failed on {os.path.basename(s)}")
+        if verbose and out.strip():
+            print(out)
+    if force or jobs or _newer(HIP_SO, objs):
+        tl = torch_lib_dir()
+        link = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HIP_SO] + objs
+        if tl:  # one HIP runtime per process: bind to the runtime torch will load (see module docstring)
+            link = ["g++", "-shared", "-fPIC", "-o", HIP_SO] + objs + ["-L", tl, "-l:libamdhip64.so", f"-Wl,-rpath,{tl}",
+                    "-Wl,--no-undefined"]
+            if os.path.exists(os.path.join(tl, "librccl.so")):
+                link += ["-l:librccl.so"]
+        _run(link)
+    return HIP_SO
+
+
+def build_host(force=False):
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.c")))
+    if not srcs:
+        return None
+    hdrs = glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    if force or _newer(HOST_SO, srcs + hdrs + [HIP_SO]):
+        _run(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-o", HOST_SO] + srcs +
+             ["-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}", "-lm"])
+    return HOST_SO
+
+
+def build_native(force=False, verbose=False):
+    hip = build_hip(force, verbose)
+    host = build_host(force)
+    return hip, host
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

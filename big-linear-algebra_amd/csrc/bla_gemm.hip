@@ -1,0 +1,353 @@
+// bla_gemm.hip -- fp32 MFMA GEMM for gfx950 (CDNA4), written for 64-wide wavefronts.
+//
+// Replaces the reference's triple loop matrix_multiply_inplace (lib/matrix.c:47-57) and,
+// through transa/transb, every transpose-multiply-transpose sandwich around it
+// (model/mnist_nn.c:267-292, lib/conv.c:221-227).
+//
+// Structure (one workgroup = WM x WN waves, one BM x BN output tile, K walked in BK slabs):
+//   * operands are staged global -> VGPR -> LDS with 16-byte loads; the loads of slab t+1 are
+//     issued before the MFMAs of slab t and written to the other LDS buffer after them
+//     (issue-early / write-late, one barrier per slab, two LDS buffers);
+//   * an operand whose K index is contiguous in memory ("KC": A of NN/NT, B of NT) lives in LDS
+//     as [row][BK+4] and a lane fetches 4 consecutive k with one ds_read_b128 (row stride
+//     BK+4 floats = odd multiple of 16 B -> the 16 lanes of a b128 group hit 16 distinct slots);
+//     an operand whose row index is contiguous ("RC": B of NN/TN, A of TN) lives as [k][rows]
+//     and a lane fetches its 4 k with four ds_read_b32 (32 consecutive floats per half-wave);
+//   * v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
+//     Register j (0..3) of a fragment holds k = 8*kk + 4*(l>>5) + j, so MFMA j of a group
+//     contracts the k pair {8kk + j, 8kk + 4 + j}; A and B use the same map, hence every k is
+//     visited exactly once (order differs from the reference's ascending chain: fp32 rounding
+//     only, see DESIGN.md "tolerances");
+//   * accumulators: TM x TN blocks of 32x32 per wave (16 VGPRs each), C/D map
+//     col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5);
+//   * blockIdx -> tile map is XCD-aware (the 8 XCDs take contiguous chunks of a grouped tile
+//     order so tiles that share A rows / B columns share an L2);
+//   * small problems use a 64x64 tile and split K over blockIdx.z into fp32 slabs that a second
+//     kernel reduces in a fixed order (deterministic, no atomics) and runs the epilogue on.
+#include "bla_internal.h"
+
+namespace bla {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+	const float* A; const float* B; float* C;
+	int M, N, K, lda, ldb, ldc;
+	int tiles_m, tiles_n, k_per_split, splits;
+	float* slab;  // splits > 1: partial products [split][M][N]
+	float alpha, beta;
+	const float* bias_row; const float* bias_col;
+	float* pre_act; int ld_pre; int act;
+	const float* relu_mask; int ld_mask;
+};
+
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
+	float v = p.alpha * acc;
+	if (p.bias_row) v += p.bias_row[r];
+	if (p.bias_col) v += p.bias_col[c];
+	if (p.pre_act) p.pre_act[(size_t)r * p.ld_pre + c] = v;
+	if (p.act == BLA_ACT_RELU) v = v < 0.f ? 0.f : v;
+	if (p.relu_mask) v = p.relu_mask[(size_t)r * p.ld_mask + c] > 0.f ? v : 0.f * v;
+	float* dst = p.C + (size_t)r * p.ldc + c;
+	if (p.beta != 0.f) v += p.beta * *dst;
+	*dst = v;
+}
+
+// ROWS x COLS tile (COLS contiguous in memory) held in registers between the global load and the LDS write.
+template <int ROWS, int COLS, int NT>
+struct TileRegs {
+	static constexpr int CPR = COLS / 4;            // 16-byte chunks per tile row
+	static constexpr int N = ROWS * COLS / 4 / NT;  // chunks per thread
+	static_assert(ROWS * COLS / 4 % NT == 0, "tile must divide over the workgroup");
+	float4 v[N];
+
+	template <bool VEC>
+	__device__ __forceinline__ void load(const float* __restrict__ g, int ld, int row0, int col0, int row_end, int col_end, int tid) {
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			int f = tid + i * NT;
+			int gr = row0 + f / CPR, gc = col0 + (f % CPR) * 4;
+			float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (gr < row_end) {
+				const float* q = g + (size_t)gr * ld + gc;
+				if (VEC && gc + 3 < col_end) {
+					x = *reinterpret_cast<const float4*>(q);
+				} else {
+					if (gc < col_end) x.x = q[0];
+					if (gc + 1 < col_end) x.y = q[1];
+					if (gc + 2 < col_end) x.z = q[2];
+					if (gc + 3 < col_end) x.w = q[3];
+				}
+			}
+			v[i] = x;
+		}
+	}
+
+	template <int STRIDE>
+	__device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			int f = tid + i * NT;
+			*reinterpret_cast<float4*>(lds + (f / CPR) * STRIDE + (f % CPR) * 4) = v[i];
+		}
+	}
+};
+
+// XCD-aware tile id: hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so give
+// XCD x the contiguous chunk [x*q, (x+1)*q) of the (grouped) tile order.  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+	int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_f32_kernel(GemmArgs p) {
+	constexpr int NT = WM * WN * 64;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	constexpr int A_ROWS = AKC ? BM : BK, A_COLS = AKC ? BK : BM, A_STRIDE = AKC ? BK + 4 : BM;
+	constexpr int B_ROWS = BKC ? BN : BK, B_COLS = BKC ? BK : BN, B_STRIDE = BKC ? BK + 4 : BN;
+	constexpr int A_SZ = A_ROWS * A_STRIDE, B_SZ = B_ROWS * B_STRIDE;
+	extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][A_SZ + B_SZ]
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l31 = lane & 31, h = lane >> 5;
+	const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+	// tile coordinates: XCD remap, then groups of 8 tile-rows walked column by column
+	int pid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+	constexpr int GROUP_M = 8;
+	int per_group = GROUP_M * p.tiles_n;
+	int first_m = (pid / per_group) * GROUP_M;
+	int gsz = min(p.tiles_m - first_m, GROUP_M);
+	int tile_m = first_m + (pid % per_group) % gsz, tile_n = (pid % per_group) / gsz;
+	const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+	const int k_begin = blockIdx.z * p.k_per_split;
+	const int k_end = min(p.K, k_begin + p.k_per_split);
+	const int nkt = (k_end - k_begin + BK - 1) / BK;
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; i++)
+#pragma unroll
+		for (int j = 0; j < TN; j++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+	TileRegs<A_ROWS, A_COLS, NT> ta;
+	TileRegs<B_ROWS, B_COLS, NT> tb;
+
+	auto gload = [&](int kt) {
+		int k0 = k_begin + kt * BK;
+		if (AKC) ta.template load<VEC>(p.A, p.lda, m0, k0, p.M, k_end, tid);
+		else     ta.template load<VEC>(p.A, p.lda, k0, m0, k_end, p.M, tid);
+		if (BKC) tb.template load<VEC>(p.B, p.ldb, n0, k0, p.N, k_end, tid);
+		else     tb.template load<VEC>(p.B, p.ldb, k0, n0, k_end, p.N, tid);
+	};
+	auto lstore = [&](int buf) {
+		float* base = lds + buf * (A_SZ + B_SZ);
+		ta.template store<A_STRIDE>(base, tid);
+		tb.template store<B_STRIDE>(base + A_SZ, tid);
+	};
+
+	if (nkt > 0) {
+		gload(0);
+		lstore(0);
+	}
+	__syncthreads();
+
+	for (int kt = 0; kt < nkt; kt++) {
+		const int cur = kt & 1;
+		if (kt + 1 < nkt) gload(kt + 1);  // in flight during the MFMAs below
+		const float* As = lds + cur * (A_SZ + B_SZ);
+		const float* Bs = As + A_SZ;
+#pragma unroll
+		for (int kk = 0; kk < BK / 8; kk++) {
+			float a[TM][4], b[TN][4];
+#pragma unroll
+			for (int i = 0; i < TM; i++) {
+				if (AKC) {
+					float4 x = *reinterpret_cast<const float4*>(As + (wm0 + i * 32 + l31) * A_STRIDE + kk * 8 + 4 * h);
+					a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
+				} else {
+#pragma unroll
+					for (int j = 0; j < 4; j++) a[i][j] = As[(kk * 8 + 4 * h + j) * A_STRIDE + wm0 + i * 32 + l31];
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < TN; i++) {
+				if (BKC) {
+					float4 x = *reinterpret_cast<const float4*>(Bs + (wn0 + i * 32 + l31) * B_STRIDE + kk * 8 + 4 * h);
+					b[i][0] = x.x; b[i][1] = x.y; b[i][2] = x.z; b[i][3] = x.w;
+				} else {
+#pragma unroll
+					for (int j = 0; j < 4; j++) b[i][j] = Bs[(kk * 8 + 4 * h + j) * B_STRIDE + wn0 + i * 32 + l31];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int in = 0; in < TN; in++)
+						acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][j], b[in][j], acc[im][in], 0, 0, 0);
+		}
+		if (kt + 1 < nkt) lstore(cur ^ 1);
+		__syncthreads();
+	}
+
+	// C/D map of the 32x32 MFMA: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+#pragma unroll
+	for (int im = 0; im < TM; im++)
+#pragma unroll
+		for (int in = 0; in < TN; in++) {
+			int col = n0 + wn0 + in * 32 + l31;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+				if (row < p.M && col < p.N) {
+					if (p.splits > 1) p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[im][in][r];
+					else epilogue_store(p, row, col, acc[im][in][r]);
+				}
+			}
+		}
+}
+
+// Sums the split-K slabs in split order (deterministic) and applies the epilogue.
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
+	size_t total = (size_t)p.M * p.N;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		float s = 0.f;
+		for (int z = 0; z < p.splits; z++) s += p.slab[(size_t)z * total + i];
+		epilogue_store(p, (int)(i / p.N), (int)(i % p.N), s);
+	}
+}
+
+struct Config { int bm, bn, bk, threads; const char* name; };
+static const Config kConfigs[] = {
+	{128, 128, 16, 256, "t128x128x16"},
+	{64, 64, 16, 256, "t64x64x16"},
+	{128, 128, 32, 256, "t128x128x32"},
+};
+static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+static int g_force_config = -1, g_force_split = 0;
+static char g_last_kernel[96] = "none";
+
+template <int BM, int BN, int BK, int WM, int WN>
+static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+	constexpr int A_SZ_KC = BM * (BK + 4), A_SZ_RC = BK * BM, B_SZ_KC = BN * (BK + 4), B_SZ_RC = BK * BN;
+	size_t lds_bytes = 2 * ((akc ? A_SZ_KC : A_SZ_RC) + (bkc ? B_SZ_KC : B_SZ_RC)) * sizeof(float);
+	dim3 block(WM * WN * 64);
+#define BLA_LAUNCH(AK, BK_, V)                                                                              \
+	do {                                                                                                    \
+		auto kern = gemm_f32_kernel<BM, BN, BK, WM, WN, AK, BK_, V>;                                        \
+		if (lds_bytes > 48 * 1024) {                                                                        \
+			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			if (e != hipSuccess) return e;                                                                  \
+		}                                                                                                   \
+		hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, a);                                             \
+		return hipGetLastError();                                                                           \
+	} while (0)
+	if (akc && !bkc) { if (vec) BLA_LAUNCH(true, false, true); else BLA_LAUNCH(true, false, false); }
+	if (akc && bkc)  { if (vec) BLA_LAUNCH(true, true, true);  else BLA_LAUNCH(true, true, false); }
+	if (!akc && !bkc){ if (vec) BLA_LAUNCH(false, false, true); else BLA_LAUNCH(false, false, false); }
+	if (vec) BLA_LAUNCH(false, true, true); else BLA_LAUNCH(false, true, false);
+#undef BLA_LAUNCH
+}
+
+}  // namespace bla
+
+using namespace bla;
+
+extern "C" {
+
+bla_status bla_gemm_set_config(int config, int split_k) {
+	BLA_REQUIRE(config >= -1 && config < kNumConfigs, BLA_ERR_INVALID, "config %d out of range [-1,%d)", config, kNumConfigs);
+	BLA_REQUIRE(split_k >= 0 && split_k <= 64, BLA_ERR_INVALID, "split_k %d out of range [0,64]", split_k);
+	g_force_config = config;
+	g_force_split = split_k;
+	return BLA_OK;
+}
+
+const char* bla_gemm_last_kernel(void) { return g_last_kernel; }
+
+bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,
+                        const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        const bla_gemm_epilogue* ep) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(m >= 0 && n >= 0 && k >= 0, BLA_ERR_INVALID, "negative dimension m=%d n=%d k=%d", m, n, k);
+	if (m == 0 || n == 0) return BLA_OK;
+	BLA_REQUIRE(C && (k == 0 || (A && B)), BLA_ERR_INVALID, "null operand pointer");
+	BLA_REQUIRE(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, BLA_ERR_INVALID,
+	            "leading dimension too small (lda=%d ldb=%d ldc=%d for m=%d n=%d k=%d ta=%d tb=%d)", lda, ldb, ldc, m, n, k, transa, transb);
+	hipStream_t s = pick_stream(stream);
+
+	GemmArgs a;
+	a.A = A; a.B = B; a.C = C; a.M = m; a.N = n; a.K = k; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+	a.alpha = ep ? ep->alpha : 1.f; a.beta = ep ? ep->beta : 0.f;
+	a.bias_row = ep ? ep->bias_row : nullptr; a.bias_col = ep ? ep->bias_col : nullptr;
+	a.pre_act = ep ? ep->pre_act : nullptr; a.ld_pre = ep ? ep->ld_pre : 0; a.act = ep ? ep->act : BLA_ACT_NONE;
+	a.relu_mask = ep ? ep->relu_mask : nullptr; a.ld_mask = ep ? ep->ld_mask : 0;
+	BLA_REQUIRE(!a.pre_act || a.ld_pre >= n, BLA_ERR_INVALID, "ld_pre %d < n %d", a.ld_pre, n);
+	BLA_REQUIRE(!a.relu_mask || a.ld_mask >= n, BLA_ERR_INVALID, "ld_mask %d < n %d", a.ld_mask, n);
+
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	int cfg = g_force_config;
+	if (cfg < 0) {
+		long big_tiles = (long)((m + 127) / 128) * ((n + 127) / 128);
+		cfg = big_tiles >= cus / 2 ? 0 : 1;
+	}
+	const Config& c = kConfigs[cfg];
+	a.tiles_m = (m + c.bm - 1) / c.bm;
+	a.tiles_n = (n + c.bn - 1) / c.bn;
+	long tiles = (long)a.tiles_m * a.tiles_n;
+	int splits = g_force_split;
+	if (splits <= 0) {
+		splits = 1;
+		if (tiles < cus && k >= 256) {  // fill the chip: aim at ~2 workgroups per CU, keep >= 128 k per split
+			long want = (2L * cus + tiles - 1) / tiles;
+			long maxs = k / 128;
+			splits = (int)(want < maxs ? want : maxs);
+			if (splits < 1) splits = 1;
+			if (splits > 32) splits = 32;
+		}
+	}
+	int kps = (k + splits - 1) / splits;
+	kps = (kps + c.bk - 1) / c.bk * c.bk;
+	if (kps == 0) kps = c.bk;
+	splits = k > 0 ? (k + kps - 1) / kps : 1;
+	a.k_per_split = kps;
+	a.splits = splits;
+	a.slab = nullptr;
+	if (splits > 1) {
+		void* ws;
+		st = ensure_workspace((size_t)splits * m * n * sizeof(float), &ws);
+		if (st) return st;
+		a.slab = (float*)ws;
+	}
+	const bool akc = !transa, bkc = transb != 0;
+	const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+	dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+	hipError_t e;
+	switch (cfg) {
+		case 0: e = launch_variant<128, 128, 16, 2, 2>(a, akc, bkc, vec, grid, s); break;
+		case 1: e = launch_variant<64, 64, 16, 2, 2>(a, akc, bkc, vec, grid, s); break;
+		default: e = launch_variant<128, 128, 32, 2, 2>(a, akc, bkc, vec, grid, s); break;
+	}
+	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
+	snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c%s_splitk%d", c.name, transa ? 't' : 'n', transb ? 't' : 'n',
+	         vec ? "_vec" : "", splits);
+	if (splits > 1) {
+		size_t total = (size_t)m * n;
+		unsigned blocks = (unsigned)((total + 255) / 256);
+		if (blocks > 2048u) blocks = 2048u;
+		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+		e = hipGetLastError();
+		if (e != hipSuccess) return hip_fail(e, "gemm_splitk_reduce_kernel launch");
+	}
+	return BLA_OK;
+}
+
+}  // extern "C"

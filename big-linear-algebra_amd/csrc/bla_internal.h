@@ -1,0 +1,40 @@
+// bla_internal.h -- shared by the HIP translation units of libbla_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/bla.h"
+
+namespace bla {
+
+struct Context {
+	bool ready = false;
+	int device = -1;
+	hipStream_t stream = nullptr;
+	void* workspace = nullptr;      // grow-only scratch (split-K slabs, reductions)
+	size_t workspace_bytes = 0;
+	int num_cus = 0;
+	char arch[64] = {0};
+};
+
+Context& ctx();
+void set_error(const char* fmt, ...);
+bla_status hip_fail(hipError_t e, const char* what);
+bla_status require_ready();
+// Scratch of at least `bytes` (device); valid until the next ensure_workspace call that grows it.
+bla_status ensure_workspace(size_t bytes, void** out);
+inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : ctx().stream; }
+
+#define BLA_HIP(call)                                               \
+	do {                                                            \
+		hipError_t _e = (call);                                     \
+		if (_e != hipSuccess) return ::bla::hip_fail(_e, #call);    \
+	} while (0)
+
+#define BLA_REQUIRE(cond, status, ...)                              \
+	do {                                                            \
+		if (!(cond)) { ::bla::set_error(__VA_ARGS__); return status; } \
+	} while (0)
+
+}  // namespace bla

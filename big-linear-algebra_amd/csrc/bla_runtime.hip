@@ -1,0 +1,226 @@
+// bla_runtime.hip -- device selection, stream, workspace, memory and event helpers
+// behind the C-ABI of include/bla.h.  No CPU fallback lives here or anywhere in
+// this library: if HIP cannot give us a gfx950 device every compute entry point
+// returns BLA_ERR_NO_DEVICE.
+#include "bla_internal.h"
+#include <cstring>
+#include <mutex>
+
+namespace bla {
+
+static Context g_ctx;
+static thread_local char g_err[512] = "no error";
+static std::mutex g_mu;
+
+Context& ctx() { return g_ctx; }
+
+void set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+bla_status hip_fail(hipError_t e, const char* what) {
+	set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+	return BLA_ERR_HIP;
+}
+
+bla_status require_ready() {
+	if (!g_ctx.ready) {
+		set_error("bla runtime not initialised: call bla_init(device) first (no CPU fallback exists)");
+		return BLA_ERR_NO_DEVICE;
+	}
+	return BLA_OK;
+}
+
+bla_status ensure_workspace(size_t bytes, void** out) {
+	if (bytes > g_ctx.workspace_bytes) {
+		// Grow-only.  Callers serialise on one stream, so freeing after a sync is safe.
+		if (g_ctx.workspace) {
+			BLA_HIP(hipDeviceSynchronize());
+			BLA_HIP(hipFree(g_ctx.workspace));
+			g_ctx.workspace = nullptr;
+			g_ctx.workspace_bytes = 0;
+		}
+		size_t want = bytes < (size_t)(64u << 20) ? (size_t)(64u << 20) : bytes;
+		BLA_HIP(hipMalloc(&g_ctx.workspace, want));
+		g_ctx.workspace_bytes = want;
+	}
+	*out = g_ctx.workspace;
+	return BLA_OK;
+}
+
+}  // namespace bla
+
+using namespace bla;
+
+extern "C" {
+
+int bla_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+bla_status bla_init(int device) {
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (g_ctx.ready && g_ctx.device == device) return BLA_OK;
+	int n = bla_device_count();
+	if (n <= 0) {
+		set_error("no HIP device visible (hipGetDeviceCount = %d); this library has no CPU path", n);
+		return BLA_ERR_NO_DEVICE;
+	}
+	BLA_REQUIRE(device >= 0 && device < n, BLA_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+	BLA_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	BLA_HIP(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		set_error("device %d is %s; libbla_hip.so carries gfx950 code objects only", device, prop.gcnArchName);
+		return BLA_ERR_NO_DEVICE;
+	}
+	if (g_ctx.ready) {  // switching device: drop the old stream/workspace
+		(void)hipStreamDestroy(g_ctx.stream);
+		if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
+		g_ctx = Context();
+	}
+	BLA_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+	g_ctx.device = device;
+	g_ctx.num_cus = prop.multiProcessorCount;
+	strncpy(g_ctx.arch, prop.gcnArchName, sizeof(g_ctx.arch) - 1);
+	g_ctx.ready = true;
+	return BLA_OK;
+}
+
+bla_status bla_shutdown(void) {
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx.ready) return BLA_OK;
+	(void)hipSetDevice(g_ctx.device);
+	(void)hipDeviceSynchronize();
+	(void)hipStreamDestroy(g_ctx.stream);
+	if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
+	g_ctx = Context();
+	return BLA_OK;
+}
+
+int bla_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
+const char* bla_last_error(void) { return g_err; }
+const char* bla_version(void) { return "bla-hip 0.1 (gfx950)"; }
+
+const char* bla_status_string(bla_status s) {
+	switch (s) {
+		case BLA_OK: return "ok";
+		case BLA_ERR_INVALID: return "invalid argument";
+		case BLA_ERR_SHAPE: return "shape mismatch";
+		case BLA_ERR_NO_DEVICE: return "no device / not initialised";
+		case BLA_ERR_HIP: return "HIP runtime error";
+		case BLA_ERR_UNDEFINED: return "undefined in the reference";
+		default: return "unknown status";
+	}
+}
+
+bla_status bla_device_name(char* buf, int buflen) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_REQUIRE(buf && buflen > 0, BLA_ERR_INVALID, "null buffer");
+	snprintf(buf, buflen, "%s (%d CUs)", g_ctx.arch, g_ctx.num_cus);
+	return BLA_OK;
+}
+
+bla_status bla_malloc(void** p, size_t bytes) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_REQUIRE(p, BLA_ERR_INVALID, "null out pointer");
+	*p = nullptr;
+	if (bytes == 0) return BLA_OK;
+	BLA_HIP(hipMalloc(p, bytes));
+	return BLA_OK;
+}
+
+bla_status bla_free(void* p) {
+	if (!p) return BLA_OK;
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_HIP(hipFree(p));
+	return BLA_OK;
+}
+
+bla_status bla_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	if (bytes == 0) return BLA_OK;
+	BLA_REQUIRE(d && h, BLA_ERR_INVALID, "null pointer in memcpy_h2d");
+	BLA_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	if (bytes == 0) return BLA_OK;
+	BLA_REQUIRE(d && h, BLA_ERR_INVALID, "null pointer in memcpy_d2h");
+	BLA_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	if (bytes == 0) return BLA_OK;
+	BLA_REQUIRE(dst && src, BLA_ERR_INVALID, "null pointer in memcpy_d2d");
+	BLA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_memset(void* d, int byte, size_t bytes, void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	if (bytes == 0) return BLA_OK;
+	BLA_REQUIRE(d, BLA_ERR_INVALID, "null pointer in memset");
+	BLA_HIP(hipMemsetAsync(d, byte, bytes, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_stream_sync(void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_HIP(hipStreamSynchronize(pick_stream(stream)));
+	return BLA_OK;
+}
+
+void* bla_default_stream(void) { return (void*)g_ctx.stream; }
+
+bla_status bla_event_create(void** ev) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_REQUIRE(ev, BLA_ERR_INVALID, "null out pointer");
+	hipEvent_t e;
+	BLA_HIP(hipEventCreate(&e));
+	*ev = (void*)e;
+	return BLA_OK;
+}
+
+bla_status bla_event_destroy(void* ev) {
+	if (!ev) return BLA_OK;
+	BLA_HIP(hipEventDestroy((hipEvent_t)ev));
+	return BLA_OK;
+}
+
+bla_status bla_event_record(void* ev, void* stream) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_REQUIRE(ev, BLA_ERR_INVALID, "null event");
+	BLA_HIP(hipEventRecord((hipEvent_t)ev, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_event_elapsed_ms(void* a, void* b, float* ms) {
+	bla_status s = require_ready();
+	if (s) return s;
+	BLA_REQUIRE(a && b && ms, BLA_ERR_INVALID, "null argument");
+	BLA_HIP(hipEventSynchronize((hipEvent_t)b));
+	BLA_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+	return BLA_OK;
+}
+
+}  // extern "C"

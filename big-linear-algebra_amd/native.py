@@ -1,0 +1,153 @@
+"""ctypes binding of csrc/libbla_hip.so (the C-ABI declared in include/bla.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libbla_hip.so")
+_lib = None
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class BlaError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"bla status {status}: {msg}")
+        self.status = status
+
+
+class Epilogue(C.Structure):
+    """struct bla_gemm_epilogue (include/bla.h)."""
+    _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("bias_row", C.c_void_p), ("bias_col", C.c_void_p),
+                ("pre_act", C.c_void_p), ("ld_pre", C.c_int), ("act", C.c_int), ("relu_mask", C.c_void_p),
+                ("ld_mask", C.c_int)]
+
+
+_VP, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+# name -> (restype, argtypes); every symbol include/bla.h declares must appear here (tests check both ways)
+SIGNATURES = {
+    "bla_init": (_I, [_I]), "bla_shutdown": (_I, []), "bla_is_initialized": (_I, []), "bla_device_count": (_I, []),
+    "bla_last_error": (C.c_char_p, []), "bla_status_string": (C.c_char_p, [_I]), "bla_version": (C.c_char_p, []),
+    "bla_device_name": (_I, [C.c_char_p, _I]),
+    "bla_malloc": (_I, [C.POINTER(_VP), _SZ]), "bla_free": (_I, [_VP]),
+    "bla_memcpy_h2d": (_I, [_VP, _VP, _SZ, _VP]), "bla_memcpy_d2h": (_I, [_VP, _VP, _SZ, _VP]),
+    "bla_memcpy_d2d": (_I, [_VP, _VP, _SZ, _VP]), "bla_memset": (_I, [_VP, _I, _SZ, _VP]),
+    "bla_stream_sync": (_I, [_VP]), "bla_default_stream": (_VP, []),
+    "bla_event_create": (_I, [C.POINTER(_VP)]), "bla_event_destroy": (_I, [_VP]), "bla_event_record": (_I, [_VP, _VP]),
+    "bla_event_elapsed_ms": (_I, [_VP, _VP, C.POINTER(_F)]),
+    "bla_gemm_f32": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, C.POINTER(Epilogue)]),
+    "bla_gemm_set_config": (_I, [_I, _I]), "bla_gemm_last_kernel": (C.c_char_p, []),
+}
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"{_SO} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "this package has no CPU fallback")
+        L = C.CDLL(_SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise BlaError(status, lib().bla_last_error().decode())
+
+
+def is_available():
+    """True when the library is built and a HIP device is visible."""
+    return os.path.exists(_SO) and lib().bla_device_count() > 0
+
+
+def init(device=0):
+    check(lib().bla_init(device))
+
+
+def sync(stream=None):
+    check(lib().bla_stream_sync(stream))
+
+
+class DeviceArray:
+    """A dense row-major fp32 matrix (or any shape) in HBM, owned via bla_malloc."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().bla_malloc(C.byref(p), max(self.nbytes, 4)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                lib().bla_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    @property
+    def ld(self):
+        return self.shape[-1]
+
+    def copy_from(self, a, stream=None):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        check(lib().bla_memcpy_h2d(self.ptr, a.ctypes.data, self.nbytes, stream))
+        sync(stream)  # pageable source must stay alive until the copy is done
+        return self
+
+    def numpy(self, stream=None):
+        out = np.empty(self.shape, self.dtype)
+        check(lib().bla_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, stream))
+        sync(stream)
+        return out
+
+    def fill_bytes(self, byte, stream=None):
+        check(lib().bla_memset(self.ptr, byte, self.nbytes, stream))
+        return self
+
+
+def to_device(a, dtype=np.float32):
+    a = np.asarray(a)
+    return DeviceArray(a.shape, dtype).copy_from(a)
+
+
+def empty(shape, dtype=np.float32):
+    return DeviceArray(shape, dtype)
+
+
+def zeros(shape, dtype=np.float32):
+    return DeviceArray(shape, dtype).fill_bytes(0)
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    return x.ptr if isinstance(x, DeviceArray) else int(x)
+
+
+def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None, bias_col=None, pre_act=None,
+         act=ACT_NONE, relu_mask=None, stream=None, m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+    """C = epilogue(alpha * op(A) op(B)) on device arrays; shapes default to the arrays' own."""
+    if m is None:
+        m = a.shape[1] if transa else a.shape[0]
+    if k is None:
+        k = a.shape[0] if transa else a.shape[1]
+    if n is None:
+        n = b.shape[0] if transb else b.shape[1]
+    kb = b.shape[1] if transb else b.shape[0]
+    if isinstance(b, DeviceArray) and kb != k:
+        raise BlaError(2, f"inner dimensions differ: {k} vs {kb}")
+    ep = Epilogue(alpha, beta, _ptr(bias_row), _ptr(bias_col), _ptr(pre_act), pre_act.ld if pre_act is not None else 0,
+                  act, _ptr(relu_mask), relu_mask.ld if relu_mask is not None else 0)
+    check(lib().bla_gemm_f32(stream, int(transa), int(transb), m, n, k, _ptr(a), lda or a.ld, _ptr(b), ldb or b.ld,
+                             _ptr(c), ldc or c.ld, C.byref(ep)))
+    return c

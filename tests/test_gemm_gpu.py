@@ -1,0 +1,157 @@
+"""GPU parity of bla_gemm_f32 (through the C-ABI) against the golden vectors the reference
+produced and against the CPU oracle on seeded inputs.
+
+Tolerance (SURVEY 8c / DESIGN.md): fp32 MFMA vs the fp64 reference,
+    normwise   ||C - ref||_F / ||ref||_F <= 1e-5
+    elementwise |C - ref|_ij <= 1e-5 * (|A| |B|)_ij   (guards cancellation near zero)
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from inputs import uniform
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    pkg.init(0)
+    pkg.lib().bla_gemm_set_config(-1, 0)
+    return pkg
+
+
+def check_gemm(ora, c, a, b, ref=None, tag=""):
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    if ref is None:
+        ref = ora.matmul(a64, b64)
+    bound = np.abs(a64) @ np.abs(b64)
+    err = np.abs(c.astype(np.float64) - ref)
+    assert (err <= RTOL * bound + 1e-30).all(), f"{tag}: elementwise excess {(err - RTOL*bound).max():.3e}"
+    nr = np.linalg.norm(ref)
+    if nr > 0:
+        assert np.linalg.norm(err) / nr <= RTOL, f"{tag}: normwise {np.linalg.norm(err)/nr:.3e}"
+
+
+def run(dev, a, b, transa=False, transb=False, **kw):
+    m = a.shape[1] if transa else a.shape[0]
+    n = b.shape[0] if transb else b.shape[1]
+    c = dev.empty((m, n)).fill_bytes(0xFF)   # NaN pattern: every element must be written
+    dev.gemm(dev.to_device(a), dev.to_device(b), c, transa=transa, transb=transb, **kw)
+    return c.numpy()
+
+
+def test_known_answers(dev, ora):
+    g = golden("gemm")
+    c = run(dev, g["kat_main_a"].astype(np.float32), g["kat_main_b"].astype(np.float32))
+    assert np.allclose(c, [[1.4, 8.5], [5.0, 19.0]], rtol=1e-6)          # main.c:20-41
+    check_gemm(ora, c, g["kat_main_a"].astype(np.float32), g["kat_main_b"].astype(np.float32), g["kat_main_c"], "kat")
+    c = run(dev, g["csv_a"].astype(np.float32), g["csv_b"].astype(np.float32))
+    check_gemm(ora, c, g["csv_a"].astype(np.float32), g["csv_b"].astype(np.float32), g["csv_c"], "csv")
+    assert np.allclose(c, [[11.5041, 2.3], [2328.603, 9.2], [43.536, 16.1]], rtol=1e-6)
+
+
+def test_golden_random_shapes(dev, ora):
+    g = golden("gemm")
+    for i, (m, k, n) in enumerate(g["shapes"]):
+        a = uniform(100 + i, (m, k), dtype=np.float32); b = uniform(200 + i, (k, n), dtype=np.float32)
+        check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
+    """Every transpose combination on every tile configuration, sizes straddling tile edges."""
+    dev.lib().bla_gemm_set_config(cfg, 0)
+    try:
+        for j, (m, k, n) in enumerate([(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128),
+                                       (257, 100, 31), (200, 260, 136)]):
+            a = uniform(10 + j, (k, m) if ta else (m, k), dtype=np.float32)
+            b = uniform(50 + j, (n, k) if tb else (k, n), dtype=np.float32)
+            c = run(dev, a, b, transa=bool(ta), transb=bool(tb))
+            check_gemm(ora, c, a.T if ta else a, b.T if tb else b, tag=f"cfg{cfg} ta{ta} tb{tb} {m}x{k}x{n}")
+    finally:
+        dev.lib().bla_gemm_set_config(-1, 0)
+
+
+@pytest.mark.parametrize("split", [2, 3, 7])
+def test_split_k(dev, ora, split):
+    dev.lib().bla_gemm_set_config(1, split)
+    try:
+        for (m, k, n) in [(10, 784, 33), (70, 1000, 70), (64, 128, 64)]:
+            a = uniform(7, (m, k), dtype=np.float32); b = uniform(8, (k, n), dtype=np.float32)
+            check_gemm(ora, run(dev, a, b), a, b, tag=f"split{split} {m}x{k}x{n}")
+            assert f"splitk" in dev.lib().bla_gemm_last_kernel().decode()
+    finally:
+        dev.lib().bla_gemm_set_config(-1, 0)
+
+
+def test_unaligned_leading_dimensions(dev, ora):
+    """ld not a multiple of 4 -> scalar-load variant; sub-matrix views via lda/ldb/ldc."""
+    big_a = uniform(1, (70, 91), dtype=np.float32); big_b = uniform(2, (91, 53), dtype=np.float32)
+    m, k, n = 60, 80, 45
+    da, db = dev.to_device(big_a), dev.to_device(big_b)
+    c = dev.zeros((m, 50))
+    dev.gemm(da, db, c, m=m, n=n, k=k, lda=91, ldb=53, ldc=50)
+    out = c.numpy()
+    check_gemm(ora, out[:, :n], big_a[:m, :k], big_b[:k, :n], tag="submatrix")
+    assert (out[:, n:] == 0).all()       # nothing outside the m x n window is touched
+    assert "_vec" not in dev.lib().bla_gemm_last_kernel().decode()
+
+
+def test_epilogue(dev, ora):
+    m, k, n = 96, 200, 130
+    a = uniform(1, (m, k), dtype=np.float32); b = uniform(2, (k, n), dtype=np.float32)
+    br = uniform(3, (m, 1), dtype=np.float32); bc = uniform(4, (1, n), dtype=np.float32)
+    mask = uniform(5, (m, n), dtype=np.float32); c0 = uniform(6, (m, n), dtype=np.float32)
+    ref = ora.matmul(a.astype(np.float64), b.astype(np.float64))
+    bound = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    # Z = W X + b (tile_columns), A = relu(Z): model/mnist_nn.c:221-224
+    z = dev.empty((m, n)); c = dev.empty((m, n))
+    dev.gemm(dev.to_device(a), dev.to_device(b), c, bias_row=dev.to_device(br), pre_act=z, act=dev.ACT_RELU)
+    zr = ora.add_tile_columns(ref, br.astype(np.float64))
+    assert (np.abs(z.numpy() - zr) <= RTOL * (bound + np.abs(br))).all()
+    assert (np.abs(c.numpy() - ora.relu(zr)) <= RTOL * (bound + np.abs(br))).all()
+    assert (c.numpy() >= 0).all()
+    # bias per column (tile_rows), relu' mask and alpha/beta accumulate
+    c = dev.to_device(c0)
+    dev.gemm(dev.to_device(a), dev.to_device(b), c, alpha=-0.5, beta=2.0, bias_col=dev.to_device(bc), relu_mask=dev.to_device(mask))
+    want = ora.hadamard(ora.add_tile_rows(-0.5 * ref, bc.astype(np.float64)), ora.relu_ddx(mask.astype(np.float64))) + 2.0 * c0
+    assert (np.abs(c.numpy() - want) <= RTOL * (bound + np.abs(bc) + 2 * np.abs(c0))).all()
+
+
+def test_argument_errors(dev):
+    a = dev.zeros((4, 4))
+    with pytest.raises(dev.BlaError) as e:
+        dev.gemm(a, a, a, lda=2)
+    assert e.value.status == 1
+    with pytest.raises(dev.BlaError):
+        dev.gemm(dev.zeros((4, 5)), dev.zeros((4, 4)), a)     # inner dimensions differ
+    dev.gemm(dev.zeros((0, 4)), a, dev.zeros((0, 4)))           # empty output: no-op, no error
+    # k == 0: empty sum -> zeros
+    c = dev.empty((3, 3)).fill_bytes(0xFF)
+    dev.gemm(dev.zeros((3, 0)), dev.zeros((0, 3)), c)
+    assert (c.numpy() == 0).all()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_large_square_sampled_rows(dev, ora, n):
+    """BASELINE config 2 sizes: oracle on a sample of output rows (full oracle would take minutes),
+    plus exactness properties that hold at any size: A @ I == A bit-for-bit and linearity in alpha."""
+    a = uniform(0xB1A5, (n, n), dtype=np.float32); b = uniform(0xB1A6, (n, n), dtype=np.float32)
+    da, db, dc = dev.to_device(a), dev.to_device(b), dev.empty((n, n))
+    c = dev.gemm(da, db, dc).numpy()
+    rows = [0, 1, n // 2 - 1, n // 2, n - 129, n - 1]
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    ref = np.zeros((n, n))
+    for r in rows:
+        ora.matmul_rows(a64, b64, ref, r, r + 1)
+    bound = np.abs(a64[rows]) @ np.abs(b64)
+    err = np.abs(c[rows] - ref[rows])
+    assert (err <= RTOL * bound).all(), (err / bound).max()
+    assert np.linalg.norm(err) / np.linalg.norm(ref[rows]) <= RTOL
+    eye = dev.to_device(np.eye(n, dtype=np.float32))
+    assert np.array_equal(dev.gemm(da, eye, dc).numpy(), a)                 # products with 0/1 are exact
+    c2 = dev.gemm(da, db, dc, alpha=2.0).numpy()
+    assert np.array_equal(c2, 2 * c)                                         # power-of-two scaling is exact
