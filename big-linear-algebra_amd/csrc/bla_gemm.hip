@@ -53,6 +53,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, 
 	*dst = v;
 }
 
+// How a tile is fetched.  All three are branch-free (loads are always issued, at clamped in-bounds
+// addresses, and out-of-range lanes are zeroed by a select) so the K loop stays one basic block.
+//   LOAD_FULL   : the whole tile is in range -- no clamps, 16-byte loads
+//   LOAD_VEC    : 16-byte loads; needs ld % 4 == 0, 16-byte aligned base and contiguous extents
+//                 that are multiples of 4 (a chunk is then either fully in or fully out of range)
+//   LOAD_SCALAR : any shape / alignment, four 4-byte loads per chunk
+enum { LOAD_FULL = 0, LOAD_VEC = 1, LOAD_SCALAR = 2 };
+
 // ROWS x COLS tile (COLS contiguous in memory) held in registers between the global load and the LDS write.
 template <int ROWS, int COLS, int NT>
 struct TileRegs {
@@ -61,25 +69,28 @@ struct TileRegs {
 	static_assert(ROWS * COLS / 4 % NT == 0, "tile must divide over the workgroup");
 	float4 v[N];
 
-	template <bool VEC>
+	// element (r,c) of the tile is g[(row0+r)*ld + col0+c]; rows >= row_end / cols >= col_end read as 0
+	template <int MODE>
 	__device__ __forceinline__ void load(const float* __restrict__ g, int ld, int row0, int col0, int row_end, int col_end, int tid) {
 #pragma unroll
 		for (int i = 0; i < N; i++) {
 			int f = tid + i * NT;
 			int gr = row0 + f / CPR, gc = col0 + (f % CPR) * 4;
-			float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (gr < row_end) {
-				const float* q = g + (size_t)gr * ld + gc;
-				if (VEC && gc + 3 < col_end) {
-					x = *reinterpret_cast<const float4*>(q);
-				} else {
-					if (gc < col_end) x.x = q[0];
-					if (gc + 1 < col_end) x.y = q[1];
-					if (gc + 2 < col_end) x.z = q[2];
-					if (gc + 3 < col_end) x.w = q[3];
-				}
+			if (MODE == LOAD_FULL) {
+				v[i] = *reinterpret_cast<const float4*>(g + (size_t)gr * ld + gc);
+			} else if (MODE == LOAD_VEC) {
+				bool ok = gr < row_end && gc < col_end;
+				const float* q = g + (size_t)min(gr, row_end - 1) * ld + min(gc, col_end - 4);
+				float4 x = *reinterpret_cast<const float4*>(q);
+				v[i] = make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
+			} else {
+				const float* q = g + (size_t)min(gr, row_end - 1) * ld;
+				bool okr = gr < row_end;
+				float x0 = q[min(gc, col_end - 1)], x1 = q[min(gc + 1, col_end - 1)];
+				float x2 = q[min(gc + 2, col_end - 1)], x3 = q[min(gc + 3, col_end - 1)];
+				v[i] = make_float4(okr && gc < col_end ? x0 : 0.f, okr && gc + 1 < col_end ? x1 : 0.f,
+				                   okr && gc + 2 < col_end ? x2 : 0.f, okr && gc + 3 < col_end ? x3 : 0.f);
 			}
-			v[i] = x;
 		}
 	}
 
@@ -100,7 +111,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MODE>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_kernel(GemmArgs p) {
 	constexpr int NT = WM * WN * 64;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -139,10 +150,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_kernel(GemmArgs p) {
 
 	auto gload = [&](int kt) {
 		int k0 = k_begin + kt * BK;
-		if (AKC) ta.template load<VEC>(p.A, p.lda, m0, k0, p.M, k_end, tid);
-		else     ta.template load<VEC>(p.A, p.lda, k0, m0, k_end, p.M, tid);
-		if (BKC) tb.template load<VEC>(p.B, p.ldb, n0, k0, p.N, k_end, tid);
-		else     tb.template load<VEC>(p.B, p.ldb, k0, n0, k_end, p.N, tid);
+		if (AKC) ta.template load<MODE>(p.A, p.lda, m0, k0, p.M, k_end, tid);
+		else     ta.template load<MODE>(p.A, p.lda, k0, m0, k_end, p.M, tid);
+		if (BKC) tb.template load<MODE>(p.B, p.ldb, n0, k0, p.N, k_end, tid);
+		else     tb.template load<MODE>(p.B, p.ldb, k0, n0, k_end, p.N, tid);
 	};
 	auto lstore = [&](int buf) {
 		float* base = lds + buf * (A_SZ + B_SZ);
@@ -156,47 +167,233 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_kernel(GemmArgs p) {
 	}
 	__syncthreads();
 
+	// fragment fetch for k-group kk (8 consecutive k) of the current LDS buffer
+	auto frags = [&](const float* As, const float* Bs, int kk, float (&a)[TM][4], float (&b)[TN][4]) {
+#pragma unroll
+		for (int i = 0; i < TM; i++) {
+			if (AKC) {
+				float4 x = *reinterpret_cast<const float4*>(As + (wm0 + i * 32 + l31) * A_STRIDE + kk * 8 + 4 * h);
+				a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) a[i][j] = As[(kk * 8 + 4 * h + j) * A_STRIDE + wm0 + i * 32 + l31];
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < TN; i++) {
+			if (BKC) {
+				float4 x = *reinterpret_cast<const float4*>(Bs + (wn0 + i * 32 + l31) * B_STRIDE + kk * 8 + 4 * h);
+				b[i][0] = x.x; b[i][1] = x.y; b[i][2] = x.z; b[i][3] = x.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) b[i][j] = Bs[(kk * 8 + 4 * h + j) * B_STRIDE + wn0 + i * 32 + l31];
+			}
+		}
+	};
+
+	constexpr int KK = BK / 8;
 	for (int kt = 0; kt < nkt; kt++) {
 		const int cur = kt & 1;
-		if (kt + 1 < nkt) gload(kt + 1);  // in flight during the MFMAs below
 		const float* As = lds + cur * (A_SZ + B_SZ);
 		const float* Bs = As + A_SZ;
+		float fa[2][TM][4], fb[2][TN][4];
+		frags(As, Bs, 0, fa[0], fb[0]);
+		gload(min(kt + 1, nkt - 1));  // in flight during the MFMAs below (the last one is a harmless re-read)
 #pragma unroll
-		for (int kk = 0; kk < BK / 8; kk++) {
-			float a[TM][4], b[TN][4];
-#pragma unroll
-			for (int i = 0; i < TM; i++) {
-				if (AKC) {
-					float4 x = *reinterpret_cast<const float4*>(As + (wm0 + i * 32 + l31) * A_STRIDE + kk * 8 + 4 * h);
-					a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
-				} else {
-#pragma unroll
-					for (int j = 0; j < 4; j++) a[i][j] = As[(kk * 8 + 4 * h + j) * A_STRIDE + wm0 + i * 32 + l31];
-				}
-			}
-#pragma unroll
-			for (int i = 0; i < TN; i++) {
-				if (BKC) {
-					float4 x = *reinterpret_cast<const float4*>(Bs + (wn0 + i * 32 + l31) * B_STRIDE + kk * 8 + 4 * h);
-					b[i][0] = x.x; b[i][1] = x.y; b[i][2] = x.z; b[i][3] = x.w;
-				} else {
-#pragma unroll
-					for (int j = 0; j < 4; j++) b[i][j] = Bs[(kk * 8 + 4 * h + j) * B_STRIDE + wn0 + i * 32 + l31];
-				}
-			}
+		for (int kk = 0; kk < KK; kk++) {
+			if (kk + 1 < KK) frags(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);  // fetch the next group under these MFMAs
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 #pragma unroll
 				for (int im = 0; im < TM; im++)
 #pragma unroll
 					for (int in = 0; in < TN; in++)
-						acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][j], b[in][j], acc[im][in], 0, 0, 0);
+						acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][im][j], fb[kk & 1][in][j], acc[im][in], 0, 0, 0);
 		}
 		if (kt + 1 < nkt) lstore(cur ^ 1);
 		__syncthreads();
 	}
 
 	// C/D map of the 32x32 MFMA: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+#pragma unroll
+	for (int im = 0; im < TM; im++)
+#pragma unroll
+		for (int in = 0; in < TN; in++) {
+			int col = n0 + wn0 + in * 32 + l31;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+				if (MODE == LOAD_FULL || (row < p.M && col < p.N)) {
+					if (p.splits > 1) p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[im][in][r];
+					else epilogue_store(p, row, col, acc[im][in][r]);
+				}
+			}
+		}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (the fast path): global_load_lds_dwordx4 moves 16 B per lane straight from
+// global memory into LDS (no VGPR staging, no ds_write), so the only thing between a K slab's
+// arrival and its MFMAs is one s_waitcnt vmcnt(0) + s_barrier per slab, and the DMA of slab t+1
+// runs under the MFMAs of slab t.  One wave-instruction writes 1 KiB of LDS contiguously
+// (wave-uniform base + lane*16), so the LDS images are lane-linear and the swizzle that keeps
+// ds_read_b128 conflict-free is applied to the per-lane SOURCE address (and again on the read):
+//   KC operand: image [rows][BK] (no padding), 16-byte chunk c of row r sits at chunk position
+//               c ^ ((r >> S) & (BK/4-1)), S = log2(16 / (BK/4)): the 16 rows a b128 lane group
+//               touches then cover all 16 slots of the 256-byte bank row;
+//   RC operand: image [BK][rows], read with ds_read_b32 of 32 consecutive floats -- no swizzle.
+// Needs K % BK == 0, 16-byte aligned rows and contiguous extents that are multiples of 4; rows /
+// columns past M / N are fetched from clamped addresses (their products are never stored).
+template <int ROWS, int BK>
+struct KcImage {  // ROWS x BK floats, K contiguous
+	static constexpr int CPR = BK / 4;                       // chunks per row: 4 (BK=16) or 8 (BK=32)
+	static constexpr int RPI = 64 / CPR;                     // rows per wave-instruction
+	static constexpr int SH = CPR == 4 ? 2 : 1;              // swizzle uses row bits [SH, SH+log2 CPR)
+	static constexpr int NINST = ROWS / RPI;                 // wave-instructions per image
+	__device__ static __forceinline__ int swz(int r, int c) { return c ^ ((r >> SH) & (CPR - 1)); }
+	// float offset of logical (row r, chunk c)
+	__device__ static __forceinline__ int off(int r, int c) { return r * BK + swz(r, c) * 4; }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_f32_glds_kernel(GemmArgs p) {
+	constexpr int NW = WM * WN;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
+	typedef KcImage<BM, BK> AI;
+	typedef KcImage<BN, BK> BI;
+	extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][A_SZ + B_SZ], all LDS in this one array
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, h = lane >> 5;
+	const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+	int pid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+	constexpr int GROUP_M = 8;
+	int per_group = GROUP_M * p.tiles_n;
+	int first_m = (pid / per_group) * GROUP_M;
+	int gsz = min(p.tiles_m - first_m, GROUP_M);
+	int tile_m = first_m + (pid % per_group) % gsz, tile_n = (pid % per_group) / gsz;
+	const int m0 = tile_m * BM, n0 = tile_n * BN;
+	const int k_begin = blockIdx.z * p.k_per_split;
+	const int k_end = min(p.K, k_begin + p.k_per_split);
+	const int nkt = (k_end - k_begin) / BK;
+
+	// Per-lane source pointers of this wave's DMA instructions for slab 0 (advance by BK per slab).
+	constexpr int A_NI = (AKC ? AI::NINST : BK * BM / 256) / NW;   // wave-instructions per wave per slab
+	constexpr int B_NI = (BKC ? BI::NINST : BK * BN / 256) / NW;
+	static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for the wave count");
+	const float* ga[A_NI];
+	const float* gb[B_NI];
+	size_t a_step, b_step;
+	if (AKC) {
+#pragma unroll
+		for (int i = 0; i < A_NI; i++) {
+			int inst = wave * A_NI + i;
+			int r = inst * AI::RPI + lane / AI::CPR, pos = lane % AI::CPR;
+			ga[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + k_begin + AI::swz(r, pos) * 4;   // swz is an involution
+		}
+		a_step = BK;
+	} else {  // A stored [k][m]: image [BK][BM]
+#pragma unroll
+		for (int i = 0; i < A_NI; i++) {
+			int f = (wave * A_NI + i) * 64 + lane;   // chunk index in the image
+			int kr = f / (BM / 4), c = (f % (BM / 4)) * 4;
+			ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(m0 + c, p.M - 4);
+		}
+		a_step = (size_t)BK * p.lda;
+	}
+	if (BKC) {
+#pragma unroll
+		for (int i = 0; i < B_NI; i++) {
+			int inst = wave * B_NI + i;
+			int r = inst * BI::RPI + lane / BI::CPR, pos = lane % BI::CPR;
+			gb[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + k_begin + BI::swz(r, pos) * 4;
+		}
+		b_step = BK;
+	} else {
+#pragma unroll
+		for (int i = 0; i < B_NI; i++) {
+			int f = (wave * B_NI + i) * 64 + lane;
+			int kr = f / (BN / 4), c = (f % (BN / 4)) * 4;
+			gb[i] = p.B + (size_t)(k_begin + kr) * p.ldb + min(n0 + c, p.N - 4);
+		}
+		b_step = (size_t)BK * p.ldb;
+	}
+
+	typedef __attribute__((address_space(3))) void* lds_ptr_t;
+	typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+	auto dma = [&](int buf) {
+		float* base = lds + buf * (A_SZ + B_SZ);
+#pragma unroll
+		for (int i = 0; i < A_NI; i++) {
+			__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+			ga[i] += a_step;
+		}
+#pragma unroll
+		for (int i = 0; i < B_NI; i++) {
+			__builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
+			gb[i] += b_step;
+		}
+	};
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; i++)
+#pragma unroll
+		for (int j = 0; j < TN; j++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+	auto frags = [&](const float* As, const float* Bs, int kk, float (&a)[TM][4], float (&b)[TN][4]) {
+#pragma unroll
+		for (int i = 0; i < TM; i++) {
+			if (AKC) {
+				float4 x = *reinterpret_cast<const float4*>(As + AI::off(wm0 + i * 32 + l31, kk * 2 + h));
+				a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) a[i][j] = As[(kk * 8 + 4 * h + j) * BM + wm0 + i * 32 + l31];
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < TN; i++) {
+			if (BKC) {
+				float4 x = *reinterpret_cast<const float4*>(Bs + BI::off(wn0 + i * 32 + l31, kk * 2 + h));
+				b[i][0] = x.x; b[i][1] = x.y; b[i][2] = x.z; b[i][3] = x.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) b[i][j] = Bs[(kk * 8 + 4 * h + j) * BN + wn0 + i * 32 + l31];
+			}
+		}
+	};
+
+	// Per slab: wait + barrier, pull the slab's fragments into registers, THEN start the DMA of the next
+	// slab (hipcc puts an s_waitcnt vmcnt(0) in front of any ds_read that follows an LDS-DMA, so the DMA
+	// must be issued after this slab's reads for it to stay in flight under the MFMAs), then the MFMAs.
+	if (nkt > 0) dma(0);
+	for (int kt = 0; kt < nkt; kt++) {
+		// slab kt has landed (own DMAs: vmcnt; other waves': barrier) and nobody still reads the other buffer
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		const float* As = lds + (kt & 1) * (A_SZ + B_SZ);
+		const float* Bs = As + A_SZ;
+		float fa[KK][TM][4], fb[KK][TN][4];
+#pragma unroll
+		for (int kk = 0; kk < KK; kk++) frags(As, Bs, kk, fa[kk], fb[kk]);
+		if (kt + 1 < nkt) dma((kt + 1) & 1);
+#pragma unroll
+		for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int in = 0; in < TN; in++)
+						acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][im][j], fb[kk][in][j], acc[im][in], 0, 0, 0);
+	}
+
 #pragma unroll
 	for (int im = 0; im < TM; im++)
 #pragma unroll
@@ -223,11 +420,14 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
 	}
 }
 
-struct Config { int bm, bn, bk, threads; const char* name; };
+struct Config { int bm, bn, bk, threads; bool glds; const char* name; };
 static const Config kConfigs[] = {
-	{128, 128, 16, 256, "t128x128x16"},
-	{64, 64, 16, 256, "t64x64x16"},
-	{128, 128, 32, 256, "t128x128x32"},
+	{128, 128, 16, 256, false, "t128x128x16"},
+	{64, 64, 16, 256, false, "t64x64x16"},
+	{128, 128, 32, 256, false, "t128x128x32"},
+	{128, 128, 16, 256, true, "glds128x128x16"},
+	{64, 64, 16, 256, true, "glds64x64x16"},
+	{128, 128, 32, 256, true, "glds128x128x32"},
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -235,13 +435,13 @@ static int g_force_config = -1, g_force_split = 0;
 static char g_last_kernel[96] = "none";
 
 template <int BM, int BN, int BK, int WM, int WN>
-static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode, dim3 grid, hipStream_t s) {
 	constexpr int A_SZ_KC = BM * (BK + 4), A_SZ_RC = BK * BM, B_SZ_KC = BN * (BK + 4), B_SZ_RC = BK * BN;
 	size_t lds_bytes = 2 * ((akc ? A_SZ_KC : A_SZ_RC) + (bkc ? B_SZ_KC : B_SZ_RC)) * sizeof(float);
 	dim3 block(WM * WN * 64);
-#define BLA_LAUNCH(AK, BK_, V)                                                                              \
+#define BLA_LAUNCH(AK, BK_, MODE_)                                                                          \
 	do {                                                                                                    \
-		auto kern = gemm_f32_kernel<BM, BN, BK, WM, WN, AK, BK_, V>;                                        \
+		auto kern = gemm_f32_kernel<BM, BN, BK, WM, WN, AK, BK_, MODE_>;                                    \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -249,10 +449,38 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, bool vec
 		hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, a);                                             \
 		return hipGetLastError();                                                                           \
 	} while (0)
-	if (akc && !bkc) { if (vec) BLA_LAUNCH(true, false, true); else BLA_LAUNCH(true, false, false); }
-	if (akc && bkc)  { if (vec) BLA_LAUNCH(true, true, true);  else BLA_LAUNCH(true, true, false); }
-	if (!akc && !bkc){ if (vec) BLA_LAUNCH(false, false, true); else BLA_LAUNCH(false, false, false); }
-	if (vec) BLA_LAUNCH(false, true, true); else BLA_LAUNCH(false, true, false);
+#define BLA_LAUNCH_MODE(AK, BK_)                                            \
+	do {                                                                    \
+		if (mode == LOAD_FULL) BLA_LAUNCH(AK, BK_, LOAD_FULL);              \
+		else if (mode == LOAD_VEC) BLA_LAUNCH(AK, BK_, LOAD_VEC);           \
+		else BLA_LAUNCH(AK, BK_, LOAD_SCALAR);                              \
+	} while (0)
+	if (akc && !bkc) BLA_LAUNCH_MODE(true, false);
+	if (akc && bkc) BLA_LAUNCH_MODE(true, true);
+	if (!akc && !bkc) BLA_LAUNCH_MODE(false, false);
+	BLA_LAUNCH_MODE(false, true);
+#undef BLA_LAUNCH_MODE
+#undef BLA_LAUNCH
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
+	size_t lds_bytes = 2 * (BM + BN) * BK * sizeof(float);
+	dim3 block(WM * WN * 64);
+#define BLA_LAUNCH(AK, BK_)                                                                                 \
+	do {                                                                                                    \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_>;                                      \
+		if (lds_bytes > 48 * 1024) {                                                                        \
+			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			if (e != hipSuccess) return e;                                                                  \
+		}                                                                                                   \
+		hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, a);                                             \
+		return hipGetLastError();                                                                           \
+	} while (0)
+	if (akc && !bkc) BLA_LAUNCH(true, false);
+	if (akc && bkc) BLA_LAUNCH(true, true);
+	if (!akc && !bkc) BLA_LAUNCH(false, false);
+	BLA_LAUNCH(false, true);
 #undef BLA_LAUNCH
 }
 
@@ -294,10 +522,21 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 	BLA_REQUIRE(!a.relu_mask || a.ld_mask >= n, BLA_ERR_INVALID, "ld_mask %d < n %d", a.ld_mask, n);
 
 	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	const bool akc = !transa, bkc = transb != 0;
+	const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+	const int a_contig = akc ? k : m, b_contig = bkc ? k : n;   // extents along the contiguous axis of each operand
+	const bool vec_ok = aligned && a_contig % 4 == 0 && b_contig % 4 == 0 && a_contig >= 4 && b_contig >= 4;
 	int cfg = g_force_config;
 	if (cfg < 0) {
 		long big_tiles = (long)((m + 127) / 128) * ((n + 127) / 128);
-		cfg = big_tiles >= cus / 2 ? 0 : 1;
+		bool big = big_tiles >= cus / 2;
+		if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;   // direct-to-LDS fast path
+		else cfg = big ? 0 : 1;
+	}
+	if (kConfigs[cfg].glds && !(vec_ok && k > 0 && k % kConfigs[cfg].bk == 0)) {
+		set_error("gemm config %d (%s) needs 16-byte aligned operands, contiguous extents %% 4 == 0 and k %% %d == 0", cfg,
+		          kConfigs[cfg].name, kConfigs[cfg].bk);
+		return BLA_ERR_INVALID;
 	}
 	const Config& c = kConfigs[cfg];
 	a.tiles_m = (m + c.bm - 1) / c.bm;
@@ -327,18 +566,25 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		if (st) return st;
 		a.slab = (float*)ws;
 	}
-	const bool akc = !transa, bkc = transb != 0;
-	const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+	int mode = LOAD_SCALAR;
+	if (vec_ok) {
+		mode = LOAD_VEC;
+		if (m % c.bm == 0 && n % c.bn == 0 && k % c.bk == 0) mode = LOAD_FULL;   // kps is a multiple of bk, so every slab is whole
+	}
 	dim3 grid((unsigned)tiles, 1, (unsigned)splits);
 	hipError_t e;
 	switch (cfg) {
-		case 0: e = launch_variant<128, 128, 16, 2, 2>(a, akc, bkc, vec, grid, s); break;
-		case 1: e = launch_variant<64, 64, 16, 2, 2>(a, akc, bkc, vec, grid, s); break;
-		default: e = launch_variant<128, 128, 32, 2, 2>(a, akc, bkc, vec, grid, s); break;
+		case 0: e = launch_variant<128, 128, 16, 2, 2>(a, akc, bkc, mode, grid, s); break;
+		case 1: e = launch_variant<64, 64, 16, 2, 2>(a, akc, bkc, mode, grid, s); break;
+		case 2: e = launch_variant<128, 128, 32, 2, 2>(a, akc, bkc, mode, grid, s); break;
+		case 3: e = launch_glds<128, 128, 16, 2, 2>(a, akc, bkc, grid, s); break;
+		case 4: e = launch_glds<64, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
-	snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c%s_splitk%d", c.name, transa ? 't' : 'n', transb ? 't' : 'n',
-	         vec ? "_vec" : "", splits);
+	static const char* kModeName[] = {"full", "vec", "scalar"};
+	snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s_splitk%d", c.name, transa ? 't' : 'n', transb ? 't' : 'n',
+	         c.glds ? "dma" : kModeName[mode], splits);
 	if (splits > 1) {
 		size_t total = (size_t)m * n;
 		unsigned blocks = (unsigned)((total + 255) / 256);

@@ -144,7 +144,7 @@ def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None
     if n is None:
         n = b.shape[0] if transb else b.shape[1]
     kb = b.shape[1] if transb else b.shape[0]
-    if isinstance(b, DeviceArray) and kb != k:
+    if isinstance(b, DeviceArray) and kb != k and ldb is None:
         raise BlaError(2, f"inner dimensions differ: {k} vs {kb}")
     ep = Epilogue(alpha, beta, _ptr(bias_row), _ptr(bias_col), _ptr(pre_act), pre_act.ld if pre_act is not None else 0,
                   act, _ptr(relu_mask), relu_mask.ld if relu_mask is not None else 0)

@@ -59,14 +59,18 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
-    """Every transpose combination on every tile configuration, sizes straddling tile edges."""
+    """Every transpose combination on every tile configuration, sizes straddling tile edges.
+    Configs 3-5 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0."""
     dev.lib().bla_gemm_set_config(cfg, 0)
+    shapes = [(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128), (257, 100, 31), (200, 260, 136)]
+    if cfg >= 3:
+        shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
+                  (384, 512, 256)]
     try:
-        for j, (m, k, n) in enumerate([(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128),
-                                       (257, 100, 31), (200, 260, 136)]):
+        for j, (m, k, n) in enumerate(shapes):
             a = uniform(10 + j, (k, m) if ta else (m, k), dtype=np.float32)
             b = uniform(50 + j, (n, k) if tb else (k, n), dtype=np.float32)
             c = run(dev, a, b, transa=bool(ta), transb=bool(tb))
@@ -97,7 +101,7 @@ def test_unaligned_leading_dimensions(dev, ora):
     out = c.numpy()
     check_gemm(ora, out[:, :n], big_a[:m, :k], big_b[:k, :n], tag="submatrix")
     assert (out[:, n:] == 0).all()       # nothing outside the m x n window is touched
-    assert "_vec" not in dev.lib().bla_gemm_last_kernel().decode()
+    assert "_scalar" in dev.lib().bla_gemm_last_kernel().decode()
 
 
 def test_epilogue(dev, ora):
