@@ -369,29 +369,68 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_glds_kernel(GemmArgs p)
 		}
 	};
 
-	// Per slab: wait + barrier, pull the slab's fragments into registers, THEN start the DMA of the next
-	// slab (hipcc puts an s_waitcnt vmcnt(0) in front of any ds_read that follows an LDS-DMA, so the DMA
-	// must be issued after this slab's reads for it to stay in flight under the MFMAs), then the MFMAs.
-	if (nkt > 0) dma(0);
-	for (int kt = 0; kt < nkt; kt++) {
-		// slab kt has landed (own DMAs: vmcnt; other waves': barrier) and nobody still reads the other buffer
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_s_barrier();
-		const float* As = lds + (kt & 1) * (A_SZ + B_SZ);
-		const float* Bs = As + A_SZ;
-		float fa[KK][TM][4], fb[KK][TN][4];
+	// Software pipeline (two LDS buffers, two fragment register sets P/Q):
+	//   step(kt): [first MFMA group of slab kt from P]
+	//             s_waitcnt vmcnt(0); s_barrier       -> slab kt+1 has landed for every wave, and every wave has
+	//                                                     finished reading slab kt (its reads fed MFMAs already issued)
+	//             ds_read slab kt+1 -> Q               (latency hidden under the remaining MFMAs of slab kt)
+	//             DMA slab kt+2 -> the buffer slab kt lived in   (issued AFTER the reads: hipcc puts an
+	//                                                     s_waitcnt vmcnt(0) before any ds_read that follows an LDS-DMA)
+	//             [remaining MFMA groups of slab kt from P]
+	// so a wave's MFMA stream only pauses for the barrier skew, never for LDS or HBM latency.
+	auto mfma_group = [&](float (&a)[KK][TM][4], float (&b)[KK][TN][4], int kk, int j) {
 #pragma unroll
-		for (int kk = 0; kk < KK; kk++) frags(As, Bs, kk, fa[kk], fb[kk]);
-		if (kt + 1 < nkt) dma((kt + 1) & 1);
+		for (int im = 0; im < TM; im++)
+#pragma unroll
+			for (int in = 0; in < TN; in++)
+				acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][im][j], b[kk][in][j], acc[im][in], 0, 0, 0);
+	};
+	auto rest = [&](float (&pa)[KK][TM][4], float (&pb)[KK][TN][4]) {
 #pragma unroll
 		for (int kk = 0; kk < KK; kk++)
 #pragma unroll
 			for (int j = 0; j < 4; j++)
+				if (kk != 0 || j != 0) mfma_group(pa, pb, kk, j);
+	};
+	// One pipeline step on slab kt (fragments in P); slab kt+1 must exist.  No branch touches the fragment
+	// registers (a conditional around the reads would make hipcc copy them at the join and wait for them).
+	auto step = [&](int kt, bool do_dma, float (&pa)[KK][TM][4], float (&pb)[KK][TN][4], float (&qa)[KK][TM][4], float (&qb)[KK][TN][4]) {
+		// sched_barrier(0) pins the order: hipcc otherwise floats the MFMAs (which touch no memory) across the
+		// barrier and the waits, e.g. hoisting the NEXT step's vmcnt(0)+barrier above this step's MFMAs.
+		mfma_group(pa, pb, 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		const float* As = lds + ((kt + 1) & 1) * (A_SZ + B_SZ);
 #pragma unroll
-				for (int im = 0; im < TM; im++)
+		for (int kk = 0; kk < KK; kk++) frags(As, As + A_SZ, kk, qa[kk], qb[kk]);
+		if (do_dma) dma(kt & 1);
+		__builtin_amdgcn_sched_barrier(0);
+		rest(pa, pb);
+		__builtin_amdgcn_sched_barrier(0);
+	};
+
+	float fa0[KK][TM][4], fb0[KK][TN][4], fa1[KK][TM][4], fb1[KK][TN][4];
+	if (nkt > 0) {
+		dma(0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
 #pragma unroll
-					for (int in = 0; in < TN; in++)
-						acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][im][j], fb[kk][in][j], acc[im][in], 0, 0, 0);
+		for (int kk = 0; kk < KK; kk++) frags(lds, lds + A_SZ, kk, fa0[kk], fb0[kk]);
+		if (nkt > 1) dma(1);
+		int kt = 0;
+		for (; kt + 2 < nkt; kt += 2) {
+			step(kt, true, fa0, fb0, fa1, fb1);               // slab kt+2 exists
+			step(kt + 1, kt + 3 < nkt, fa1, fb1, fa0, fb0);
+		}
+		if (nkt - kt == 2) {
+			step(kt, false, fa0, fb0, fa1, fb1);
+			mfma_group(fa1, fb1, 0, 0);
+			rest(fa1, fb1);
+		} else {
+			mfma_group(fa0, fb0, 0, 0);
+			rest(fa0, fb0);
+		}
 	}
 
 #pragma unroll
