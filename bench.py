@@ -39,22 +39,26 @@ def cpu_baseline_gemm(n, target_seconds=12.0):
     import oracle
     import ref
     a = uniform(0xB1A5, (n, n)); b = uniform(0xB1A6, (n, n))          # fp64, the reference's element type
-    est_gflops = 0.4
-    rows = int(max(8, min(n, target_seconds * est_gflops * 1e9 / (2.0 * n * n))))
-    rows = (rows // 8) * 8
-    a_slice = np.ascontiguousarray(a[:rows])
-    if ref.available():
-        kind = "reference"
-        t0 = time.perf_counter()
-        c = ref.matmul_inplace(a_slice, b)                             # matrix_multiply_inplace, lib/matrix.c:47-57
-        dt = time.perf_counter() - t0
-    else:
-        kind = "port"
-        oracle.build()
+    def run(rows):
+        a_slice = np.ascontiguousarray(a[:rows])
+        if ref.available():
+            t0 = time.perf_counter()
+            c = ref.matmul_inplace(a_slice, b)                         # matrix_multiply_inplace, lib/matrix.c:47-57
+            return c, time.perf_counter() - t0
         c = np.zeros((rows, n))
         t0 = time.perf_counter()
         oracle.matmul_rows(a_slice, b, c, 0, rows)
-        dt = time.perf_counter() - t0
+        return c, time.perf_counter() - t0
+
+    kind = "reference" if ref.available() else "port"
+    if kind == "port":
+        oracle.build()
+    # calibrate on 2 rows (the loop is cache-hostile: the rate falls ~10x between N=1024 and N=4096), then size
+    # the sample to ~target_seconds of CPU work
+    _, t2 = run(2)
+    rows = int(max(2, min(n, target_seconds / (t2 / 2))))
+    rows = max(2, (rows // 2) * 2)
+    c, dt = run(rows)
     gflops = 2.0 * rows * n * n / dt / 1e9
     return {"value": round(gflops, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind, "dtype": "f64",
             "sample": f"{rows} of {n} output rows of the same {n}^3 product, gcc -O2, {dt:.1f} s",

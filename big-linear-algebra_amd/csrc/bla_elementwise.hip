@@ -1,0 +1,375 @@
+// bla_elementwise.hip -- HBM-bound kernels for the loops of lib/matrix.c:59-205 and lib/util.c:7-55
+// (model/mnist_nn.c:38-73 carries identical copies of relu / softmax).
+//
+// All of these move 4..12 bytes per element and do O(1) flops per element: the roofline is HBM
+// (8 TB/s spec, ~6.3 TB/s achievable), so the design rules are the coalescing ones:
+//   * flat elementwise ops: 16 bytes per lane (float4) when the base is 16-byte aligned, grid capped at
+//     8 workgroups per CU with a grid-stride loop;
+//   * anything that walks a matrix "the short way" in the reference (column-major loops at
+//     lib/matrix.c:150-158,189-195) is re-indexed so that consecutive lanes touch consecutive addresses;
+//   * reductions accumulate in fp64 inside a thread, combine by wave shuffles (64 lanes) then LDS, and finish
+//     in a fixed order (deterministic, no atomics); sums therefore sit closer to the fp64 reference than a
+//     sequential fp32 chain would.
+#include "bla_internal.h"
+#include <cmath>
+
+namespace bla {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;  // 256 CUs x 8
+
+static inline unsigned grid_for(size_t work_items) {
+	size_t b = (work_items + kThreads - 1) / kThreads;
+	if (b < 1) b = 1;
+	if (b > kMaxBlocks) b = kMaxBlocks;
+	return (unsigned)b;
+}
+
+// ---- flat elementwise ---------------------------------------------------------------------------
+enum { OP_SCALE, OP_ADD, OP_MUL, OP_AXPY, OP_RELU, OP_RELU_DDX };
+
+template <int OP>
+__device__ __forceinline__ float ew_apply(float a, float b, float f) {
+	switch (OP) {
+		case OP_SCALE: return a * f;                   // lib/matrix.c:59-63
+		case OP_ADD: return a + b;                     // lib/matrix.c:65-69
+		case OP_MUL: return a * b;                     // lib/matrix.c:95-103
+		case OP_AXPY: return a + f * b;                // matrix_scale(g, lr) then matrix_add(w, g): model/mnist_nn.c:303-315
+		case OP_RELU: return a < 0.f ? 0.f : a;        // lib/util.c:7-13
+		default: return a > 0.f ? 1.f : 0.f;           // model/mnist_nn.c:47-51
+	}
+}
+
+template <int OP, bool BINARY>
+__global__ void __launch_bounds__(kThreads) ew_kernel(float* __restrict__ a, const float* __restrict__ b, float f, size_t n, int vec_ok) {
+	size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	size_t n4 = vec_ok ? n / 4 : 0;
+	float4* a4 = reinterpret_cast<float4*>(a);
+	const float4* b4 = reinterpret_cast<const float4*>(b);
+	for (size_t i = tid; i < n4; i += stride) {
+		float4 x = a4[i], y = BINARY ? b4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+		x.x = ew_apply<OP>(x.x, y.x, f); x.y = ew_apply<OP>(x.y, y.y, f);
+		x.z = ew_apply<OP>(x.z, y.z, f); x.w = ew_apply<OP>(x.w, y.w, f);
+		a4[i] = x;
+	}
+	for (size_t i = n4 * 4 + tid; i < n; i += stride) a[i] = ew_apply<OP>(a[i], BINARY ? b[i] : 0.f, f);
+}
+
+template <int OP, bool BINARY>
+static bla_status launch_ew(void* stream, float* a, const float* b, float f, size_t n) {
+	bla_status st = require_ready();
+	if (st) return st;
+	if (n == 0) return BLA_OK;
+	BLA_REQUIRE(a && (!BINARY || b), BLA_ERR_INVALID, "null operand");
+	int vec_ok = ((uintptr_t)a % 16 == 0) && (!BINARY || (uintptr_t)b % 16 == 0);
+	hipLaunchKernelGGL((ew_kernel<OP, BINARY>), dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, pick_stream(stream), a, b, f, n, vec_ok);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+// ---- broadcasts: a[r][c] += b[r][c % b_cols] (tile columns) / a[r][c] += b[c] (tile rows) ----------------
+__global__ void __launch_bounds__(kThreads) tile_columns_kernel(float* __restrict__ a, const float* __restrict__ b, int rows, int cols, int b_cols) {
+	size_t n = (size_t)rows * cols;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		int r = (int)(i / cols), c = (int)(i % cols);
+		a[i] += b[(size_t)r * b_cols + c % b_cols];
+	}
+}
+
+__global__ void __launch_bounds__(kThreads) tile_rows_kernel(float* __restrict__ a, const float* __restrict__ b, int rows, int cols) {
+	size_t n = (size_t)rows * cols;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i % cols];
+}
+
+// ---- transpose: 64x64 tile through LDS, stride 65 so both the row-wise write and the column-wise read are
+// conflict-free for ds_*_b32 (bank = dword index mod 32 per 32-lane half) ---------------------------------
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+	__shared__ float tile[64][65];
+	int tiles_c = (cols + 63) / 64;
+	int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+	int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;  // 64 x 4
+	for (int y = ly; y < 64; y += 4) {
+		int r = tr * 64 + y, c = tc * 64 + lx;
+		if (r < rows && c < cols) tile[y][lx] = in[(size_t)r * cols + c];
+	}
+	__syncthreads();
+	for (int y = ly; y < 64; y += 4) {
+		int c = tc * 64 + y, r = tr * 64 + lx;   // out is cols x rows
+		if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[lx][y];
+	}
+}
+
+// ---- reductions ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+	return v;
+}
+
+// block-wide sum of (s0, s1), result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& s0, double& s1) {
+	__shared__ double sh[2][kThreads / 64];
+	s0 = wave_sum(s0); s1 = wave_sum(s1);
+	int w = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		s0 = 0; s1 = 0;
+		for (int i = 0; i < kThreads / 64; i++) { s0 += sh[0][i]; s1 += sh[1][i]; }
+	}
+	__syncthreads();
+}
+
+enum { RED_SUM_SQ = 0, RED_MAX = 1, RED_SUM_AND_SQ = 2 };
+
+// stage 1: per-block partials (sum, sum of squares, max); stage 2 (one block) folds them in block order
+__global__ void __launch_bounds__(kThreads) reduce_stage1_kernel(const float* __restrict__ m, size_t n, double* __restrict__ part) {
+	double s = 0, q = 0;
+	float mx = -INFINITY;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		float v = m[i];
+		s += v; q += (double)v * v; mx = fmaxf(mx, v);
+	}
+	__shared__ float shm[kThreads / 64];
+	mx = wave_max(mx);
+	if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+	block_sum2(s, q);
+	if (threadIdx.x == 0) {
+		for (int i = 0; i < kThreads / 64; i++) mx = fmaxf(mx, shm[i]);
+		part[3 * blockIdx.x + 0] = s; part[3 * blockIdx.x + 1] = q; part[3 * blockIdx.x + 2] = mx;
+	}
+}
+
+// out[0] = result of `what`; for zscore also out[1], out[2] = mean, stdev (sqrtf on the variance as lib/matrix.c:179)
+__global__ void __launch_bounds__(64) reduce_stage2_kernel(const double* __restrict__ part, int nparts, size_t n, int what, float* __restrict__ out) {
+	double s = 0, q = 0;
+	float mx = -INFINITY;
+	for (int i = threadIdx.x; i < nparts; i += 64) { s += part[3 * i]; q += part[3 * i + 1]; mx = fmaxf(mx, (float)part[3 * i + 2]); }
+	s = wave_sum(s); q = wave_sum(q); mx = wave_max(mx);
+	if (threadIdx.x == 0) {
+		if (what == RED_SUM_SQ) out[0] = (float)sqrt(q);          // frobenius_norm, lib/matrix.c:150-158
+		else if (what == RED_MAX) out[0] = mx;                    // max_value, lib/matrix.c:160-168
+		else {                                                    // matrix_z_score_normalize, lib/matrix.c:170-185
+			double mean = s / (double)n;
+			out[0] = (float)mean;
+			out[1] = sqrtf((float)(q / (double)n - mean * mean));
+		}
+	}
+}
+
+__global__ void __launch_bounds__(kThreads) zscore_apply_kernel(float* __restrict__ m, size_t n, const float* __restrict__ stats) {
+	float mean = stats[0], sd = stats[1];
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m[i] = (m[i] - mean) / sd;
+}
+
+// out[c] = sum_r m[r*cols + c]  (matrix_row_sum, lib/matrix.c:123-133): lanes across columns, coalesced
+__global__ void __launch_bounds__(kThreads) row_sum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ out) {
+	int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= cols) return;
+	double s = 0;
+	for (int r = 0; r < rows; r++) s += m[(size_t)r * cols + c];
+	out[c] = (float)s;
+}
+
+// out[i] = sum_{j<len} m[i*stride + j]: one wave per output.
+//   stride = cols -> true row sums (the documented intent of matrix_col_sum, lib/matrix.c:135-137)
+//   stride = rows -> matrix_col_sum AS WRITTEN (lib/matrix.c:138-148), defined only when rows <= cols
+__global__ void __launch_bounds__(kThreads) window_sum_kernel(const float* __restrict__ m, int count, int len, int stride, float* __restrict__ out) {
+	int i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (i >= count) return;
+	double s = 0;
+	for (int j = lane; j < len; j += 64) s += m[(size_t)i * stride + j];
+	s = wave_sum(s);
+	if (lane == 0) out[i] = (float)s;
+}
+
+// ---- softmax -----------------------------------------------------------------------------------------
+// per column (lib/util.c:15-34): one thread per column, rows walked with stride cols -> coalesced across lanes.
+// Optional fused tail for the trainer: out = (softmax - y) * scale (model/mnist_nn.c:263-268).
+__global__ void __launch_bounds__(kThreads) softmax_cols_kernel(float* __restrict__ d, int rows, int cols, const float* __restrict__ y, float scale, float* __restrict__ grad) {
+	int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= cols) return;
+	float mx = -INFINITY;
+	for (int r = 0; r < rows; r++) mx = fmaxf(mx, d[(size_t)r * cols + c]);
+	float s = 0.f;
+	for (int r = 0; r < rows; r++) {
+		float e = expf(d[(size_t)r * cols + c] - mx);
+		d[(size_t)r * cols + c] = e;
+		s += e;
+	}
+	for (int r = 0; r < rows; r++) {
+		float p = d[(size_t)r * cols + c] / s;
+		d[(size_t)r * cols + c] = p;
+		if (grad) grad[(size_t)r * cols + c] = (p - y[(size_t)r * cols + c]) * scale;
+	}
+}
+
+// per row (lib/util.c:36-55): one wave per row
+__global__ void __launch_bounds__(kThreads) softmax_rows_kernel(float* __restrict__ d, int rows, int cols) {
+	int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (r >= rows) return;
+	float* row = d + (size_t)r * cols;
+	float mx = -INFINITY;
+	for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, row[j]);
+	mx = wave_max(mx);
+	mx = __shfl(mx, 0, 64);
+	double s = 0;
+	for (int j = lane; j < cols; j += 64) {
+		float e = expf(row[j] - mx);
+		row[j] = e;
+		s += e;
+	}
+	s = wave_sum(s);
+	float sf = (float)__shfl(s, 0, 64);
+	for (int j = lane; j < cols; j += 64) row[j] /= sf;
+}
+
+static bla_status reduce_common(void* stream, const float* m, size_t n, int what, float* d_out) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(d_out && (n == 0 || m), BLA_ERR_INVALID, "null operand");
+	hipStream_t s = pick_stream(stream);
+	unsigned blocks = grid_for(n ? n : 1);
+	if (blocks > 1024) blocks = 1024;
+	void* ws;
+	st = ensure_workspace((size_t)blocks * 3 * sizeof(double), &ws);
+	if (st) return st;
+	hipLaunchKernelGGL(reduce_stage1_kernel, dim3(blocks), dim3(kThreads), 0, s, m, n, (double*)ws);
+	hipLaunchKernelGGL(reduce_stage2_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)blocks, n, what, d_out);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+}  // namespace bla
+
+using namespace bla;
+
+extern "C" {
+
+bla_status bla_scale_f32(void* stream, float* d_m, size_t n, float f) { return launch_ew<OP_SCALE, false>(stream, d_m, nullptr, f, n); }
+bla_status bla_add_f32(void* stream, float* d_a, const float* d_b, size_t n) { return launch_ew<OP_ADD, true>(stream, d_a, d_b, 0.f, n); }
+bla_status bla_hadamard_f32(void* stream, float* d_a, const float* d_b, size_t n) { return launch_ew<OP_MUL, true>(stream, d_a, d_b, 0.f, n); }
+bla_status bla_axpy_f32(void* stream, float* d_y, const float* d_x, float alpha, size_t n) { return launch_ew<OP_AXPY, true>(stream, d_y, d_x, alpha, n); }
+bla_status bla_relu_f32(void* stream, float* d, size_t n) { return launch_ew<OP_RELU, false>(stream, d, nullptr, 0.f, n); }
+bla_status bla_relu_ddx_f32(void* stream, float* d, size_t n) { return launch_ew<OP_RELU_DDX, false>(stream, d, nullptr, 0.f, n); }
+
+bla_status bla_add_tile_columns_f32(void* stream, float* d_a, int a_rows, int a_cols, const float* d_b, int b_cols) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(a_rows >= 0 && a_cols >= 0 && b_cols > 0, BLA_ERR_INVALID, "bad shape %dx%d tiled by %d columns", a_rows, a_cols, b_cols);
+	if (a_rows == 0 || a_cols == 0) return BLA_OK;
+	BLA_REQUIRE(d_a && d_b, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(tile_columns_kernel, dim3(grid_for((size_t)a_rows * a_cols)), dim3(kThreads), 0, pick_stream(stream), d_a, d_b, a_rows, a_cols, b_cols);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_add_tile_rows_f32(void* stream, float* d_a, int a_rows, int a_cols, const float* d_b) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(a_rows >= 0 && a_cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", a_rows, a_cols);
+	if (a_rows == 0 || a_cols == 0) return BLA_OK;
+	BLA_REQUIRE(d_a && d_b, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(tile_rows_kernel, dim3(grid_for((size_t)a_rows * a_cols)), dim3(kThreads), 0, pick_stream(stream), d_a, d_b, a_rows, a_cols);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_transpose_f32(void* stream, const float* d_in, float* d_out, int rows, int cols) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	if (rows == 0 || cols == 0) return BLA_OK;
+	BLA_REQUIRE(d_in && d_out && d_in != d_out, BLA_ERR_INVALID, "transpose needs distinct non-null in/out");
+	unsigned tiles = (unsigned)(((rows + 63) / 64) * ((cols + 63) / 64));
+	hipLaunchKernelGGL(transpose_kernel, dim3(tiles), dim3(256), 0, pick_stream(stream), d_in, d_out, rows, cols);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_row_sum_f32(void* stream, const float* d_m, int rows, int cols, float* d_out) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	if (cols == 0) return BLA_OK;
+	BLA_REQUIRE(d_out && (rows == 0 || d_m), BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(row_sum_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d_m, rows, cols, d_out);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_col_sum_f32(void* stream, const float* d_m, int rows, int cols, float* d_out, int mode) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	BLA_REQUIRE(mode == BLA_COLSUM_AS_WRITTEN || mode == BLA_COLSUM_INTENDED, BLA_ERR_INVALID, "bad col_sum mode %d", mode);
+	if (mode == BLA_COLSUM_AS_WRITTEN && rows > cols) {
+		set_error("matrix_col_sum as written reads out of bounds for %dx%d (rows > cols, lib/matrix.c:144): undefined in the reference", rows, cols);
+		return BLA_ERR_UNDEFINED;
+	}
+	if (rows == 0) return BLA_OK;
+	BLA_REQUIRE(d_out && (cols == 0 || d_m), BLA_ERR_INVALID, "null operand");
+	int stride = mode == BLA_COLSUM_AS_WRITTEN ? rows : cols;
+	hipLaunchKernelGGL(window_sum_kernel, dim3((rows + 3) / 4), dim3(kThreads), 0, pick_stream(stream), d_m, rows, cols, stride, d_out);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_frobenius_f32(void* stream, const float* d_m, size_t n, float* d_out) { return reduce_common(stream, d_m, n, RED_SUM_SQ, d_out); }
+bla_status bla_max_f32(void* stream, const float* d_m, size_t n, float* d_out) { return reduce_common(stream, d_m, n, RED_MAX, d_out); }
+
+bla_status bla_zscore_f32(void* stream, float* d_m, size_t n) {
+	bla_status st = require_ready();
+	if (st) return st;
+	if (n == 0) return BLA_OK;
+	void* ws;
+	st = ensure_workspace(1024 * 3 * sizeof(double) + 64, &ws);   // reduce_common's partials + 2 floats after them
+	if (st) return st;
+	float* stats = (float*)((char*)ws + 1024 * 3 * sizeof(double));
+	st = reduce_common(stream, d_m, n, RED_SUM_AND_SQ, stats);
+	if (st) return st;
+	hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(n)), dim3(kThreads), 0, pick_stream(stream), d_m, n, stats);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_softmax_cols_f32(void* stream, float* d, int rows, int cols) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	if (rows == 0 || cols == 0) return BLA_OK;
+	BLA_REQUIRE(d, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d, rows, cols,
+	                   (const float*)nullptr, 0.f, (float*)nullptr);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_softmax_cols_grad_f32(void* stream, float* d, int rows, int cols, const float* d_y, float scale, float* d_grad) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	if (rows == 0 || cols == 0) return BLA_OK;
+	BLA_REQUIRE(d && d_y && d_grad, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d, rows, cols, d_y, scale, d_grad);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_softmax_rows_f32(void* stream, float* d, int rows, int cols) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
+	if (rows == 0 || cols == 0) return BLA_OK;
+	BLA_REQUIRE(d, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(kThreads), 0, pick_stream(stream), d, rows, cols);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+}  // extern "C"

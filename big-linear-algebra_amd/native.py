@@ -38,6 +38,21 @@ SIGNATURES = {
     "bla_event_elapsed_ms": (_I, [_VP, _VP, C.POINTER(_F)]),
     "bla_gemm_f32": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, C.POINTER(Epilogue)]),
     "bla_gemm_set_config": (_I, [_I, _I]), "bla_gemm_last_kernel": (C.c_char_p, []),
+    "bla_scale_f32": (_I, [_VP, _VP, _SZ, _F]), "bla_add_f32": (_I, [_VP, _VP, _VP, _SZ]),
+    "bla_hadamard_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_axpy_f32": (_I, [_VP, _VP, _VP, _F, _SZ]),
+    "bla_relu_f32": (_I, [_VP, _VP, _SZ]), "bla_relu_ddx_f32": (_I, [_VP, _VP, _SZ]),
+    "bla_add_tile_columns_f32": (_I, [_VP, _VP, _I, _I, _VP, _I]), "bla_add_tile_rows_f32": (_I, [_VP, _VP, _I, _I, _VP]),
+    "bla_transpose_f32": (_I, [_VP, _VP, _VP, _I, _I]), "bla_row_sum_f32": (_I, [_VP, _VP, _I, _I, _VP]),
+    "bla_col_sum_f32": (_I, [_VP, _VP, _I, _I, _VP, _I]), "bla_frobenius_f32": (_I, [_VP, _VP, _SZ, _VP]),
+    "bla_max_f32": (_I, [_VP, _VP, _SZ, _VP]), "bla_zscore_f32": (_I, [_VP, _VP, _SZ]),
+    "bla_softmax_cols_f32": (_I, [_VP, _VP, _I, _I]), "bla_softmax_rows_f32": (_I, [_VP, _VP, _I, _I]),
+    "bla_softmax_cols_grad_f32": (_I, [_VP, _VP, _I, _I, _VP, _F, _VP]),
+    "bla_conv_out_hw": (_I, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "bla_im2col_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]), "bla_col2im_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
+    "bla_kernels_to_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]), "bla_matrix_to_kernels_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]),
+    "bla_reshape_channels_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I]), "bla_reshape_matrix_channels_f32": (_I, [_VP, _VP, _VP, _I, _I]),
+    "bla_conv_forward_f32": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f32": (_I, [_VP] * 9 + [_I] * 6),
+    "bla_group_norm_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f32": (_I, [_VP] * 6 + [_I] * 3),
 }
 
 

@@ -113,6 +113,58 @@ BLA_API bla_status bla_gemm_set_config(int config, int split_k);
 /* Name of the kernel variant the last bla_gemm_f32 call launched (for profiles/). */
 BLA_API const char* bla_gemm_last_kernel(void);
 
+/* ---- elementwise / broadcast / transpose / reductions: lib/matrix.c:59-205, lib/util.c:7-55 -------------
+ * All operate in place on device memory exactly like their reference counterparts operate on host
+ * memory; n = rows*cols.  HBM-bound; sums accumulate in fp64 and are rounded to fp32 once. */
+BLA_API bla_status bla_scale_f32(void* stream, float* d_m, size_t n, float f);                 /* matrix_scale, lib/matrix.c:59-63 */
+BLA_API bla_status bla_add_f32(void* stream, float* d_a, const float* d_b, size_t n);          /* matrix_add: a += b, lib/matrix.c:65-69 */
+BLA_API bla_status bla_hadamard_f32(void* stream, float* d_a, const float* d_b, size_t n);     /* matrix_multiply_elementwise, lib/matrix.c:95-103 (shape check is the caller's) */
+BLA_API bla_status bla_axpy_f32(void* stream, float* d_y, const float* d_x, float alpha, size_t n); /* y += alpha*x: matrix_scale+matrix_add pair, model/mnist_nn.c:303-315 */
+BLA_API bla_status bla_relu_f32(void* stream, float* d, size_t n);                             /* relu, lib/util.c:7-13 */
+BLA_API bla_status bla_relu_ddx_f32(void* stream, float* d, size_t n);                         /* relu_ddx, model/mnist_nn.c:47-51 */
+BLA_API bla_status bla_add_tile_columns_f32(void* stream, float* d_a, int a_rows, int a_cols, const float* d_b, int b_cols); /* lib/matrix.c:189-195 */
+BLA_API bla_status bla_add_tile_rows_f32(void* stream, float* d_a, int a_rows, int a_cols, const float* d_b);                /* lib/matrix.c:199-205 */
+BLA_API bla_status bla_transpose_f32(void* stream, const float* d_in, float* d_out, int rows, int cols);  /* out (cols x rows) = in^T; matrix_transpose, lib/matrix.c:105-118 */
+BLA_API bla_status bla_row_sum_f32(void* stream, const float* d_m, int rows, int cols, float* d_out);     /* 1 x cols, matrix_row_sum, lib/matrix.c:123-133 */
+/* matrix_col_sum, lib/matrix.c:138-148.  AS_WRITTEN reproduces out[i] = sum_{j<cols} flat[i*rows+j] and returns
+ * BLA_ERR_UNDEFINED where the reference reads out of bounds (rows > cols); INTENDED gives true row sums. */
+enum { BLA_COLSUM_AS_WRITTEN = 0, BLA_COLSUM_INTENDED = 1 };
+BLA_API bla_status bla_col_sum_f32(void* stream, const float* d_m, int rows, int cols, float* d_out, int mode);
+BLA_API bla_status bla_frobenius_f32(void* stream, const float* d_m, size_t n, float* d_out);  /* d_out[0] = sqrt(sum x^2), lib/matrix.c:150-158 */
+BLA_API bla_status bla_max_f32(void* stream, const float* d_m, size_t n, float* d_out);        /* d_out[0] = max (-inf when empty), lib/matrix.c:160-168 */
+BLA_API bla_status bla_zscore_f32(void* stream, float* d_m, size_t n);                         /* matrix_z_score_normalize, lib/matrix.c:170-185 */
+BLA_API bla_status bla_softmax_cols_f32(void* stream, float* d, int rows, int cols);           /* softmax per column, lib/util.c:15-34 */
+BLA_API bla_status bla_softmax_rows_f32(void* stream, float* d, int rows, int cols);           /* softmax_row_wise, lib/util.c:36-55 */
+/* softmax per column, then d_grad = (softmax - y) * scale in the same pass (model/mnist_nn.c:234,263-268) */
+BLA_API bla_status bla_softmax_cols_grad_f32(void* stream, float* d, int rows, int cols, const float* d_y, float scale, float* d_grad);
+
+/* ---- convolution stages, lib/conv.c.  Images are contiguous [C][H][W]; kernels [F][C][k][k]; workspaces are
+ * the reference's ConvData members (lib/conv.h:6-11): im2col [Ho*Wo][k*k*C], kernel_matrix [k*k*C][F],
+ * product [Ho*Wo][F], output [F][Ho][Wo].  TF "SAME" padding, Ho = ceil((float)H/stride) (lib/conv.c:13-28,55-56). */
+BLA_API bla_status bla_conv_out_hw(int h, int w, int stride, int* ho, int* wo);
+BLA_API bla_status bla_im2col_f32(void* stream, const float* d_x, float* d_out, int h, int w, int k, int c_in, int stride);       /* _im2col, lib/conv.c:8-77 */
+/* _col2im, lib/conv.c:80-135: defined for stride 1 only (returns BLA_ERR_UNDEFINED otherwise) */
+BLA_API bla_status bla_col2im_f32(void* stream, const float* d_cols, float* d_out, int h, int w, int k, int c_n, int stride);
+BLA_API bla_status bla_kernels_to_matrix_f32(void* stream, const float* d_kern, float* d_mat, int f_n, int c_n, int k);          /* _reshape_kernels_matrix, lib/conv.c:138-153 */
+BLA_API bla_status bla_matrix_to_kernels_f32(void* stream, const float* d_mat, float* d_kern, int f_n, int c_n, int k);          /* _reshape_matrix_kernels, lib/conv.c:156-171 */
+/* The two channel reshapes keep the reference's names, argument order AND as-written direction:
+ * reshape_channels_matrix(channels, matrix) writes channels <- matrix; reshape_matrix_channels(matrix, channels) writes matrix <- channels. */
+BLA_API bla_status bla_reshape_channels_matrix_f32(void* stream, float* d_channels, const float* d_matrix, int c_n, int hw);     /* lib/conv.c:174-187 */
+BLA_API bla_status bla_reshape_matrix_channels_f32(void* stream, float* d_matrix, const float* d_channels, int c_n, int hw);     /* lib/conv.c:190-203 */
+/* conv(), lib/conv.c:205-212, intended composition (GEMM result reaches output; as written the last step overwrites product
+ * from the stale output and never writes output -- the host layer offers that literal mode too). */
+BLA_API bla_status bla_conv_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_im2col, float* d_kmat, float* d_product,
+                                        float* d_output, int h, int w, int k, int c_in, int f_n, int stride);
+/* conv_ddx(), lib/conv.c:214-229, intended composition; stride must be 1. */
+BLA_API bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float* d_im2col, const float* d_kmat, float* d_del_q,
+                                         float* d_del_kmat, float* d_del_kern, float* d_del_col, float* d_del_x, int h, int w, int k, int c_in,
+                                         int f_n, int stride);
+/* group_norm / group_norm_ddx, lib/norm.c:5-93, on [C][H*W]; quirk Q3 kept (epsilon == 0, "stdevs" holds the variance,
+ * out = (x - mean) / variance).  Note the reference's argument orders (lib/norm.h:6-7). */
+BLA_API bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw);
+BLA_API bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means,
+                                          const float* d_stdevs, int channels, int group_size, int hw);
+
 #ifdef __cplusplus
 }
 #endif

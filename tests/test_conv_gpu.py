@@ -1,0 +1,120 @@
+"""GPU parity of the lib/conv.c stages and lib/norm.c group norm against the reference's golden
+vectors (tests/golden/conv.npz, norm.npz).  Index-only stages (im2col, kernel/channel reshapes) are
+bit-exact; col2im is bit-identical to the fp32 oracle (same addition order); GEMM-bearing stages use
+the GEMM tolerance 1e-5 * (|A||B|)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from inputs import uniform
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    pkg.init(0)
+    return pkg
+
+
+def call(dev, name, *args):
+    """DeviceArray arguments are passed by pointer and kept alive until the call has been issued
+    (a temporary's bla_free would otherwise hand its memory to the next allocation)."""
+    raw = [a.ptr if isinstance(a, dev.DeviceArray) else a for a in args]
+    dev.native.check(getattr(dev.lib(), name)(None, *raw))
+
+
+def conv_case(i, cfg):
+    h, w, cin, cout, k, s = [int(v) for v in cfg]
+    seed = 1000 + 10 * i
+    return (h, w, cin, cout, k, s, seed, uniform(seed, (cin, h, w), -1, 1, F32), uniform(seed + 1, (cout, cin, k, k), -0.3, 0.3, F32))
+
+
+def test_conv_forward_stages(dev, ora):
+    g = golden("conv")
+    for i, cfg in enumerate(g["cfgs"]):
+        h, w, cin, cout, k, s, seed, x, kern = conv_case(i, cfg)
+        ho, wo = C.c_int(), C.c_int()
+        dev.native.check(dev.lib().bla_conv_out_hw(h, w, s, C.byref(ho), C.byref(wo)))
+        assert (ho.value, wo.value) == ora.out_hw(h, w, s)
+        hw, kkc = ho.value * wo.value, k * k * cin
+        dx, dk = dev.to_device(x), dev.to_device(kern)
+        im, km, pr, out = dev.empty((hw, kkc)), dev.empty((kkc, cout)), dev.empty((hw, cout)), dev.empty((cout, ho.value, wo.value))
+        call(dev, "bla_conv_forward_f32", dx, dk, im, km, pr, out, h, w, k, cin, cout, s)
+        g.check(f"c{i}_im2col", im.numpy(), exact=True)          # fp32 inputs are exact in fp64: index-only stage is bit-exact
+        g.check(f"c{i}_kmat", km.numpy(), exact=True)
+        bound = np.abs(im.numpy().astype(np.float64)) @ np.abs(km.numpy().astype(np.float64))
+        ref = ora.conv_intended(x.astype(np.float64), kern.astype(np.float64), s)
+        assert (np.abs(pr.numpy() - ref["product"]) <= 1e-5 * bound + 1e-30).all()
+        g.check(f"c{i}_product", pr.numpy(), rtol=0, atol=1e-5 * bound.max())
+        assert np.array_equal(out.numpy().reshape(cout, hw), pr.numpy().T)      # output is a pure re-indexing of product
+        g.check(f"c{i}_output", out.numpy(), rtol=0, atol=1e-5 * bound.max())
+        # stand-alone stages
+        im2 = dev.empty((hw, kkc)); call(dev, "bla_im2col_f32", dx, im2, h, w, k, cin, s)
+        assert np.array_equal(im2.numpy(), im.numpy())
+        kb = dev.empty((cout, cin, k, k)); call(dev, "bla_matrix_to_kernels_f32", km, kb, cout, cin, k)
+        assert np.array_equal(kb.numpy(), kern)
+        back = dev.empty((hw, cout)); call(dev, "bla_reshape_matrix_channels_f32", back, out, cout, hw)
+        assert np.array_equal(back.numpy(), pr.numpy())
+
+
+def test_col2im_and_backward(dev, ora):
+    g = golden("conv")
+    for i, cfg in enumerate(g["cfgs"]):
+        h, w, cin, cout, k, s, seed, x, kern = conv_case(i, cfg)
+        hw, kkc = h * w, k * k * cin
+        if s != 1:
+            o = dev.empty((cin, h, w))
+            assert dev.lib().bla_col2im_f32(None, dev.zeros((hw, kkc)).ptr, o.ptr, h, w, k, cin, s) == 5     # undefined (Q5)
+            assert dev.lib().bla_conv_backward_f32(None, *([o.ptr] * 9), h, w, k, cin, cout, s) == 5
+            continue
+        cols = uniform(seed + 2, (hw, kkc), -1, 1, F32)
+        o = dev.empty((cin, h, w)); call(dev, "bla_col2im_f32", dev.to_device(cols), o, h, w, k, cin, 1)
+        assert np.array_equal(o.numpy(), ora.col2im(cols, cin, h, w, k))       # same fp32 additions in the same order
+        g.check(f"c{i}_col2im", o.numpy(), rtol=2e-6, atol=2e-6)
+        # intended conv_ddx chain
+        fw = ora.conv_intended(x, kern, 1)
+        del_y = uniform(seed + 3, (cout, h, w), -1, 1, F32)
+        dq, dkm, dkern = dev.empty((hw, cout)), dev.empty((kkc, cout)), dev.empty((cout, cin, k, k))
+        dcol, dxx = dev.empty((hw, kkc)), dev.empty((cin, h, w))
+        call(dev, "bla_conv_backward_f32", dev.to_device(del_y), dev.to_device(fw["im2col"]), dev.to_device(fw["kmat"]),
+             dq, dkm, dkern, dcol, dxx, h, w, k, cin, cout, 1)
+        g.check(f"c{i}_ddx_del_q", dq.numpy(), exact=True)
+        im64, km64, dq64 = fw["im2col"].astype(np.float64), fw["kmat"].astype(np.float64), dq.numpy().astype(np.float64)
+        b1 = np.abs(im64.T) @ np.abs(dq64)
+        g.check(f"c{i}_ddx_del_kmat", dkm.numpy(), rtol=0, atol=1e-5 * b1.max())
+        assert np.array_equal(dkern.numpy().reshape(cout, kkc), dkm.numpy().T)
+        b2 = np.abs(dq64) @ np.abs(km64.T)
+        g.check(f"c{i}_ddx_del_col", dcol.numpy(), rtol=0, atol=1e-5 * b2.max())
+        g.check(f"c{i}_ddx_del_x", dxx.numpy(), rtol=0, atol=1e-5 * b2.max() * k * k)
+        # adjoint identity <im2col(x), y> == <x, col2im(y)> (defines col2im independently of the reference)
+        xr = uniform(seed + 5, (cin, h, w), -1, 1, F32)
+        imx = dev.empty((hw, kkc)); call(dev, "bla_im2col_f32", dev.to_device(xr), imx, h, w, k, cin, 1)
+        lhs = float((imx.numpy().astype(np.float64) * cols).sum()); rhs = float((xr.astype(np.float64) * o.numpy()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * (np.abs(imx.numpy()).astype(np.float64) * np.abs(cols)).sum()
+
+
+def test_group_norm(dev, ora):
+    g = golden("norm")
+    for i, (c, gs, h, w) in enumerate(g["cfgs"]):
+        c, gs, h, w = int(c), int(gs), int(h), int(w)
+        x = uniform(2000 + i, (c, h, w), -1, 3, F32)
+        ng = (c + gs - 1) // gs
+        out, sd, mu = dev.empty((c, h, w)), dev.empty((ng,)), dev.empty((ng,))
+        call(dev, "bla_group_norm_f32", dev.to_device(x), out, sd, mu, c, gs, h * w)
+        assert np.allclose(mu.numpy(), g[f"n{i}_means"], rtol=2e-6, atol=1e-7)
+        assert np.allclose(sd.numpy(), g[f"n{i}_stdevs"], rtol=5e-6)
+        g.check(f"n{i}_out", out.numpy(), rtol=1e-5, atol=1e-6)
+        up = uniform(2100 + i, (c, h, w), -1, 1, F32)
+        dest = dev.empty((c, h, w))
+        call(dev, "bla_group_norm_ddx_f32", dev.to_device(up), dest, dev.to_device(x), mu, sd, c, gs, h * w)
+        ref = g[f"n{i}_ddx"]
+        assert (np.abs(dest.numpy() - ref) <= 2e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max()).all()
+    # the documented probe: group {1..8} -> mean 4.5, "stdev" (variance) 5.25, out[0] = -0.6667
+    out, sd, mu = dev.empty((2, 2, 2)), dev.empty((1,)), dev.empty((1,))
+    call(dev, "bla_group_norm_f32", dev.to_device(np.arange(1, 9, dtype=F32).reshape(2, 2, 2)), out, sd, mu, 2, 32, 4)
+    assert mu.numpy()[0] == 4.5 and sd.numpy()[0] == 5.25 and abs(out.numpy().ravel()[0] + 0.6667) < 1e-4
+    assert np.allclose(out.numpy(), g["probe_out"], rtol=1e-6)
