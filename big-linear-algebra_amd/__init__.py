@@ -8,6 +8,8 @@ from . import build as _build  # noqa: F401
 from .native import (BlaError, DeviceArray, lib, init, is_available, gemm, Epilogue,  # noqa: F401
                      to_device, empty, zeros, sync, ACT_NONE, ACT_RELU)
 
+from . import native, mnist_nn  # noqa: F401,E402
+
 build_native = _build.build_native
 __all__ = ["BlaError", "DeviceArray", "lib", "init", "is_available", "gemm", "Epilogue", "to_device", "empty",
            "zeros", "sync", "build_native", "ACT_NONE", "ACT_RELU"]

@@ -1,0 +1,218 @@
+// bla_mnist.hip -- device-resident trainer for the reference's MNIST-NN (model/mnist_nn.c): the hot loop
+// :218-315 (scale, 3 x {GEMM, bias, activation}, loss gradient, 5 transposed GEMMs, bias gradients, SGD
+// update) with parameters, activations and gradients resident in HBM and no host round trip per batch.
+//
+// Why this exists beside the drop-in matrix.h: the reference program mutates ->data on the host between
+// library calls (mnist_nn.c:38-51,204-217), so the host-coherent API can never keep tensors on the device;
+// samples/s is therefore measured on this trainer, which reproduces the same arithmetic step by step
+// (tests/test_mnist_gpu.py pins it to the golden vectors the reference produced).
+//
+// Data layout: samples are COLUMNS (input [n0][B], one-hot labels [n3][B], model/mnist_nn.c:199,209).
+// Parameters live in ONE flat fp32 bucket in the order W1,b1,W2,b2,W3,b3 (row-major, the CSV order of
+// data/mnist_nn/*.csv); gradients in a second bucket with the same layout -- the unit a data-parallel
+// all-reduce exchanges (SUM over ranks: every weight gradient is a plain sum over batch columns, no 1/B,
+// model/mnist_nn.c:260-293), after which every rank applies the identical update.
+//
+// Fusions relative to the reference's call sequence (all are re-orderings of independent elementwise work):
+//   matrix_multiply + matrix_add_tile_columns + clone_matrix + relu  -> one GEMM with bias/ReLU epilogue that
+//        stores Z (pre-activation) and A                                        (:221-229)
+//   clone + scale(-1) + add + scale(1/n0) around softmax              -> softmax kernel with gradient tail (:233-268)
+//   transpose + multiply + transpose                                  -> NT / TN GEMM                     (:267-292)
+//   clone + relu_ddx + multiply_elementwise                           -> GEMM epilogue mask on Z          (:276-278,287-289)
+//   6 x {clip (no-op), scale(lr), add}                                -> one axpy over the flat bucket     (:296-315)
+#include "bla_internal.h"
+#include <vector>
+
+struct bla_mnist_nn {
+	int n[4];
+	int batch;
+	size_t off[6];        // offsets of W1,b1,W2,b2,W3,b3 in the buckets
+	size_t count;         // total parameters
+	float* params; float* grads; bool own_buckets;
+	float* x;             // scaled input [n0][B]
+	float* x_raw; float* y;   // optional resident input/label buffers (graph replay)
+	float *z1, *a1, *z2, *a2, *z3, *a3, *dz3, *dz2, *dz1;
+	std::vector<void*> owned;
+	hipGraph_t graph; hipGraphExec_t graph_exec; bool graph_ready; int graph_colsum; float graph_lr;
+};
+
+using namespace bla;
+
+static bla_status dev_alloc(bla_mnist_nn* nn, float** p, size_t floats) {
+	void* q = nullptr;
+	BLA_HIP(hipMalloc(&q, (floats ? floats : 1) * sizeof(float)));
+	nn->owned.push_back(q);
+	*p = (float*)q;
+	return BLA_OK;
+}
+
+extern "C" {
+
+bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(out && sizes, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(batch > 0 && sizes[0] > 0 && sizes[1] > 0 && sizes[2] > 0 && sizes[3] > 0, BLA_ERR_INVALID, "bad layer sizes / batch");
+	bla_mnist_nn* nn = new bla_mnist_nn();
+	for (int i = 0; i < 4; i++) nn->n[i] = sizes[i];
+	nn->batch = batch;
+	size_t o = 0;
+	for (int l = 0; l < 3; l++) {
+		nn->off[2 * l] = o; o += (size_t)sizes[l + 1] * sizes[l];
+		nn->off[2 * l + 1] = o; o += (size_t)sizes[l + 1];
+	}
+	// keep every W 16-byte aligned inside the bucket when the sizes allow it (784*256, 256, ... all are multiples of 4
+	// for the reference architecture; odd architectures fall back to the scalar-load GEMM variant automatically)
+	nn->count = o;
+	nn->own_buckets = true;
+	nn->graph_ready = false;
+	const size_t B = batch;
+	st = dev_alloc(nn, &nn->params, o); if (st) return st;
+	st = dev_alloc(nn, &nn->grads, o); if (st) return st;
+	st = dev_alloc(nn, &nn->x, sizes[0] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->x_raw, sizes[0] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->y, sizes[3] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->z1, sizes[1] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->a1, sizes[1] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->z2, sizes[2] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->a2, sizes[2] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->z3, sizes[3] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->a3, sizes[3] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->dz3, sizes[3] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->dz2, sizes[2] * B); if (st) return st;
+	st = dev_alloc(nn, &nn->dz1, sizes[1] * B); if (st) return st;
+	BLA_HIP(hipMemset(nn->params, 0, o * sizeof(float)));
+	BLA_HIP(hipMemset(nn->grads, 0, o * sizeof(float)));
+	void* ws;   // split-K slabs: grow the shared workspace now so that no step (or graph capture) ever reallocates
+	st = ensure_workspace((size_t)64 << 20, &ws); if (st) return st;
+	*out = nn;
+	return BLA_OK;
+}
+
+bla_status bla_mnist_nn_destroy(bla_mnist_nn* nn) {
+	if (!nn) return BLA_OK;
+	if (nn->graph_ready) { (void)hipGraphExecDestroy(nn->graph_exec); (void)hipGraphDestroy(nn->graph); }
+	for (void* p : nn->owned) (void)hipFree(p);
+	delete nn;
+	return BLA_OK;
+}
+
+size_t bla_mnist_nn_param_count(const bla_mnist_nn* nn) { return nn ? nn->count : 0; }
+float* bla_mnist_nn_params(bla_mnist_nn* nn) { return nn ? nn->params : nullptr; }
+float* bla_mnist_nn_grads(bla_mnist_nn* nn) { return nn ? nn->grads : nullptr; }
+float* bla_mnist_nn_input(bla_mnist_nn* nn) { return nn ? nn->x_raw : nullptr; }
+float* bla_mnist_nn_labels(bla_mnist_nn* nn) { return nn ? nn->y : nullptr; }
+
+bla_status bla_mnist_nn_use_buckets(bla_mnist_nn* nn, float* d_params, float* d_grads) {
+	BLA_REQUIRE(nn && d_params && d_grads, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(!nn->graph_ready, BLA_ERR_INVALID, "buckets cannot change after a graph was captured");
+	BLA_HIP(hipMemcpy(d_params, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToDevice));
+	nn->params = d_params; nn->grads = d_grads; nn->own_buckets = false;
+	return BLA_OK;
+}
+
+bla_status bla_mnist_nn_set_params(bla_mnist_nn* nn, const float* h_flat) {
+	BLA_REQUIRE(nn && h_flat, BLA_ERR_INVALID, "null argument");
+	BLA_HIP(hipMemcpy(nn->params, h_flat, nn->count * sizeof(float), hipMemcpyHostToDevice));
+	return BLA_OK;
+}
+
+bla_status bla_mnist_nn_get_params(bla_mnist_nn* nn, float* h_flat) {
+	BLA_REQUIRE(nn && h_flat, BLA_ERR_INVALID, "null argument");
+	BLA_HIP(hipDeviceSynchronize());
+	BLA_HIP(hipMemcpy(h_flat, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToHost));
+	return BLA_OK;
+}
+
+/* which: 0..8 = z1,a1,z2,a2,z3,a3,dz3,dz2,dz1 (device pointers, [rows][B]) -- for parity tests */
+bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which, float** d_ptr, int* rows) {
+	BLA_REQUIRE(nn && d_ptr && rows && which >= 0 && which < 9, BLA_ERR_INVALID, "bad argument");
+	float* p[9] = {nn->z1, nn->a1, nn->z2, nn->a2, nn->z3, nn->a3, nn->dz3, nn->dz2, nn->dz1};
+	int r[9] = {nn->n[1], nn->n[1], nn->n[2], nn->n[2], nn->n[3], nn->n[3], nn->n[3], nn->n[2], nn->n[1]};
+	*d_ptr = p[which]; *rows = r[which];
+	return BLA_OK;
+}
+
+/* Forward + backward for one batch: fills the gradient bucket (un-scaled sums over the batch columns).
+ * d_x_raw: [n0][B] pixels 0..255 (scaled by 1/255.0F here, model/mnist_nn.c:218); d_y: one-hot [n3][B].
+ * NULL for either means "use the trainer's resident input / label buffer". */
+bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	if (!d_x_raw) d_x_raw = nn->x_raw;
+	if (!d_y) d_y = nn->y;
+	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
+	if (colsum_mode == BLA_COLSUM_AS_WRITTEN && (n1 > B || n2 > B || n3 > B)) {
+		set_error("matrix_col_sum as written is out of bounds for layer sizes %d/%d/%d at batch %d (rows > cols, SURVEY Q2)", n1, n2, n3, B);
+		return BLA_ERR_UNDEFINED;
+	}
+	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
+	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
+	float *dW1 = nn->grads + nn->off[0], *db1 = nn->grads + nn->off[1], *dW2 = nn->grads + nn->off[2], *db2 = nn->grads + nn->off[3];
+	float *dW3 = nn->grads + nn->off[4], *db3 = nn->grads + nn->off[5];
+	hipStream_t s = pick_stream(stream);
+
+	// input scale, :218 (1 / 255.0F is a float expression)
+	BLA_HIP(hipMemcpyAsync(nn->x, d_x_raw, (size_t)n0 * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+	st = bla_scale_f32(s, nn->x, (size_t)n0 * B, 1 / 255.0F); if (st) return st;
+
+	bla_gemm_epilogue ep = {1.f, 0.f, b1, nullptr, nn->z1, B, BLA_ACT_RELU, nullptr, 0};
+	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, nn->x, B, nn->a1, B, &ep); if (st) return st;           // :221-224
+	ep.bias_row = b2; ep.pre_act = nn->z2;
+	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;          // :226-229
+	ep.bias_row = b3; ep.pre_act = nn->z3; ep.act = BLA_ACT_NONE;
+	st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;          // :231-233
+	// softmax per column, then dZ3 = (A3 - Y) * (1/n0): :234,260-268 (scale = 1 / (double) LAYER_INPUT_SIZE)
+	st = bla_softmax_cols_grad_f32(s, nn->a3, n3, B, d_y, (float)(1 / (double)n0), nn->dz3); if (st) return st;
+
+	st = bla_gemm_f32(s, 0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, nullptr); if (st) return st;    // dW3 = dZ3 . A2^T, :267-270
+	st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st;                           // :271
+	bla_gemm_epilogue em = {1.f, 0.f, nullptr, nullptr, nullptr, 0, BLA_ACT_NONE, nn->z2, B};
+	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st;         // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278
+	st = bla_gemm_f32(s, 0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, nullptr); if (st) return st;    // :279-281
+	st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st;                           // :282
+	em.relu_mask = nn->z1;
+	st = bla_gemm_f32(s, 1, 0, n1, B, n2, W2, n1, nn->dz2, B, nn->dz1, B, &em); if (st) return st;         // :284-289
+	st = bla_gemm_f32(s, 0, 1, n1, n0, B, nn->dz1, B, nn->x, B, dW1, n0, nullptr); if (st) return st;     // :290-292
+	return bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode);                                            // :293
+}
+
+/* params += lr * grads over the whole bucket: the six {clip (no-op at INFINITY), scale, add} triples of :296-315.
+ * The reference's learn rate is the float -0.02 (:186). */
+bla_status bla_mnist_nn_apply(bla_mnist_nn* nn, void* stream, float lr) {
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	return bla_axpy_f32(stream, nn->params, nn->grads, lr, nn->count);
+}
+
+bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode) {
+	bla_status st = bla_mnist_nn_forward_backward(nn, stream, d_x_raw, d_y, colsum_mode);
+	if (st) return st;
+	return bla_mnist_nn_apply(nn, stream, lr);
+}
+
+/* Capture one whole step (resident input/label buffers -> updated parameters) into a hipGraph and replay it:
+ * the step is ~25 launches of a few microseconds each, i.e. launch-bound when issued one by one.
+ * with_update = 0 captures forward+backward only (data-parallel: the all-reduce sits between the two halves). */
+bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float lr, int colsum_mode, int with_update) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	hipStream_t s = pick_stream(stream);
+	if (!nn->graph_ready || nn->graph_colsum != colsum_mode * 2 + with_update || nn->graph_lr != lr) {
+		if (nn->graph_ready) { (void)hipGraphExecDestroy(nn->graph_exec); (void)hipGraphDestroy(nn->graph); nn->graph_ready = false; }
+		BLA_HIP(hipStreamSynchronize(s));
+		BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+		st = bla_mnist_nn_forward_backward(nn, s, nullptr, nullptr, colsum_mode);
+		if (!st && with_update) st = bla_mnist_nn_apply(nn, s, lr);
+		hipError_t e = hipStreamEndCapture(s, &nn->graph);
+		if (st) { if (e == hipSuccess) (void)hipGraphDestroy(nn->graph); return st; }
+		if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+		BLA_HIP(hipGraphInstantiate(&nn->graph_exec, nn->graph, nullptr, nullptr, 0));
+		nn->graph_ready = true; nn->graph_colsum = colsum_mode * 2 + with_update; nn->graph_lr = lr;
+	}
+	BLA_HIP(hipGraphLaunch(nn->graph_exec, s));
+	return BLA_OK;
+}
+
+}  // extern "C"

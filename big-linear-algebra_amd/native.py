@@ -53,6 +53,13 @@ SIGNATURES = {
     "bla_reshape_channels_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I]), "bla_reshape_matrix_channels_f32": (_I, [_VP, _VP, _VP, _I, _I]),
     "bla_conv_forward_f32": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f32": (_I, [_VP] * 9 + [_I] * 6),
     "bla_group_norm_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f32": (_I, [_VP] * 6 + [_I] * 3),
+    "bla_mnist_nn_create": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_mnist_nn_destroy": (_I, [_VP]),
+    "bla_mnist_nn_param_count": (_SZ, [_VP]), "bla_mnist_nn_params": (_VP, [_VP]), "bla_mnist_nn_grads": (_VP, [_VP]),
+    "bla_mnist_nn_input": (_VP, [_VP]), "bla_mnist_nn_labels": (_VP, [_VP]),
+    "bla_mnist_nn_use_buckets": (_I, [_VP, _VP, _VP]), "bla_mnist_nn_set_params": (_I, [_VP, _VP]),
+    "bla_mnist_nn_get_params": (_I, [_VP, _VP]), "bla_mnist_nn_activation": (_I, [_VP, _I, C.POINTER(_VP), C.POINTER(_I)]),
+    "bla_mnist_nn_forward_backward": (_I, [_VP, _VP, _VP, _VP, _I]), "bla_mnist_nn_apply": (_I, [_VP, _VP, _F]),
+    "bla_mnist_nn_train_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]), "bla_mnist_nn_graph_step": (_I, [_VP, _VP, _F, _I, _I]),
 }
 
 

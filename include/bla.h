@@ -165,6 +165,32 @@ BLA_API bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_
 BLA_API bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means,
                                           const float* d_stdevs, int channels, int group_size, int hw);
 
+/* ---- device-resident MNIST-NN trainer: the hot loop of model/mnist_nn.c:218-315 with everything in HBM -------
+ * sizes = {n0, n1, n2, n3} (784, 256, 128, 10 in the reference, model/mnist_nn.c:25-28); samples are columns.
+ * Parameters sit in one flat bucket ordered W1,b1,W2,b2,W3,b3 (each row-major), gradients in a second bucket of
+ * the same layout (un-scaled sums over the batch columns).  Data parallelism = SUM-all-reduce the gradient
+ * bucket between bla_mnist_nn_forward_backward and bla_mnist_nn_apply.
+ * colsum_mode: BLA_COLSUM_AS_WRITTEN reproduces matrix_col_sum literally (needs n_i <= batch, else
+ * BLA_ERR_UNDEFINED); BLA_COLSUM_INTENDED uses true row sums (required for sharded batches). */
+typedef struct bla_mnist_nn bla_mnist_nn;
+BLA_API bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes /* [4] */, int batch);
+BLA_API bla_status bla_mnist_nn_destroy(bla_mnist_nn* nn);
+BLA_API size_t bla_mnist_nn_param_count(const bla_mnist_nn* nn);
+BLA_API float* bla_mnist_nn_params(bla_mnist_nn* nn);     /* device pointer, param_count floats */
+BLA_API float* bla_mnist_nn_grads(bla_mnist_nn* nn);      /* device pointer, param_count floats */
+BLA_API float* bla_mnist_nn_input(bla_mnist_nn* nn);      /* resident raw-pixel buffer [n0][batch] (used when d_x_raw == NULL) */
+BLA_API float* bla_mnist_nn_labels(bla_mnist_nn* nn);     /* resident one-hot buffer [n3][batch] (used when d_y == NULL) */
+/* Adopt caller-owned buckets (e.g. tensors a collective library registered); current parameters are copied over. */
+BLA_API bla_status bla_mnist_nn_use_buckets(bla_mnist_nn* nn, float* d_params, float* d_grads);
+BLA_API bla_status bla_mnist_nn_set_params(bla_mnist_nn* nn, const float* h_flat);
+BLA_API bla_status bla_mnist_nn_get_params(bla_mnist_nn* nn, float* h_flat);
+BLA_API bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which /* 0..8: z1,a1,z2,a2,z3,a3,dz3,dz2,dz1 */, float** d_ptr, int* rows);
+BLA_API bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode);
+BLA_API bla_status bla_mnist_nn_apply(bla_mnist_nn* nn, void* stream, float lr /* reference: (float)-0.02 */);
+BLA_API bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode);
+/* Same step from the resident buffers, captured once into a hipGraph and replayed (launch-bound otherwise). */
+BLA_API bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float lr, int colsum_mode, int with_update);
+
 #ifdef __cplusplus
 }
 #endif

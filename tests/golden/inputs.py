@@ -44,6 +44,12 @@ class Golden:
     def __getitem__(self, name):
         return self.z[name]
 
+    def mean_abs(self, name):
+        """Mean |value| of a recorded output (full or digest): the natural absolute scale for a tolerance."""
+        if self.is_digest(name):
+            return float(self.z[name + "__asum"]) / float(np.prod(self.z[name + "__shape"]))
+        return float(np.abs(self.z[name]).mean())
+
     def is_digest(self, name):
         return (name + "__sum") in self.z.files
 
