@@ -10,6 +10,12 @@ square fp32 matrix_multiply, N = 4096, both operands and the output resident in 
 its own replica (a square GEMM has no exchange step: "replicas only") and the
 value is the aggregate over ranks.
 
+Secondary workload, measured in the same run and reported under "secondary" in the same JSON line (the second
+half of BASELINE.json's metric, "MNIST-NN training samples/sec @1/2/4/8 GPUs"): model/mnist_nn.c's 784-256-128-10
+SGD step on the device-resident trainer, 256 samples per GPU (weak scaling; global batch = 256 x N), synthetic
+pixels/labels resident in HBM, data parallel with ONE RCCL SUM all-reduce of the flat 235,146-float gradient bucket
+per step between backward and the update (torch.distributed "nccl" backend = RCCL over xGMI).
+
 Rank 0 prints ONE JSON line carrying, besides the contract keys, `roofline` (dominant kernel vs the
 gfx950 fp32 MFMA peak, timed with HIP events on the launch stream) and `cpu_baseline` (the reference's
 own loop, lib/matrix.c:47-57, timed on this host on a bounded slice of the same product).
@@ -65,6 +71,81 @@ def cpu_baseline_gemm(n, target_seconds=12.0):
             "full_product_seconds_extrapolated": round(2.0 * n ** 3 / (gflops * 1e9), 1)}, c, rows
 
 
+def cpu_baseline_mnist(batch, target_seconds=8.0):
+    """The reference's training step (model/mnist_nn.c:218-315 restated in oracle/, fp64, 1 core) on the same
+    synthetic batch shape."""
+    import oracle
+    from inputs import randint
+    oracle.build()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    params = [z[n].astype(np.float64) for n in ["w1", "b1", "w2", "b2", "w3", "b3"]]
+    x_raw = randint(7, (784, batch), 256).astype(np.float64)
+    lab = randint(8, (batch,), 10); y = np.zeros((10, batch)); y[lab, np.arange(batch)] = 1
+    t0 = time.perf_counter(); steps = 0
+    while True:
+        params, _, _ = oracle.mnist_step(params, x_raw, y, colsum_intended=True)
+        steps += 1
+        if time.perf_counter() - t0 > target_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * batch / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port", "dtype": "f64",
+            "sample": f"{steps} SGD steps at batch {batch} (model/mnist_nn.c:218-315 restated), gcc -O2, {dt:.1f} s"}
+
+
+def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_batch=256):
+    """samples/s of the data-parallel MNIST-NN step; returns the "secondary" object (rank 0) or None."""
+    from inputs import randint
+    mn = bla.mnist_nn
+    nn = mn.MnistNN(per_gpu_batch, colsum_mode=mn.COLSUM_INTENDED)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])   # the reference's trained weights (identical on all ranks)
+    gB = per_gpu_batch * world
+    x_raw = randint(7, (784, gB), 256).astype(np.float32)
+    lab = randint(8, (gB,), 10); y = np.zeros((10, gB), np.float32); y[lab, np.arange(gB)] = 1
+    lo, hi = mn.shard_columns(gB, world, rank)
+    nn.load_batch(np.ascontiguousarray(x_raw[:, lo:hi]), np.ascontiguousarray(y[:, lo:hi]))
+    grads_t = None
+    if dist is not None:
+        import torch
+        params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
+        grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        nn.use_buckets(params_t.data_ptr(), grads_t.data_ptr())
+
+        def step():
+            mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
+                                  lambda: nn.apply(stream=stream), dist)
+    else:
+        def step():
+            nn.graph_step(stream=stream, with_update=True)
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    p = bla.mnist_nn.flatten_params(nn.get_params()) if dist is None else None
+    if p is not None:
+        assert np.isfinite(p).all()
+    if rank != 0:
+        return None
+    flop_per_sample = 1007104   # GEMMs only, fwd 469,504 + bwd 537,600 (SURVEY 8d)
+    sps = steps * gB / wall
+    return {"metric": "MNIST-NN training samples/sec", "value": round(sps, 1), "unit": "samples/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4), "scaling": "weak",
+            "config": {"workload": "model/mnist_nn.c 784-256-128-10 SGD step, device-resident trainer", "per_gpu_batch": per_gpu_batch,
+                       "global_batch": gB, "parallelism": f"dp{world}",
+                       "exchange": "none" if world == 1 else "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"},
+            "gemm_flop_rate_tflops": round(sps * flop_per_sample / 1e12, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +153,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=4096, help="square GEMM size (BASELINE configs[1]: 1024..8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mnist-steps", type=int, default=300, help="timed steps of the secondary MNIST-NN workload (0 = skip)")
+    ap.add_argument("--mnist-warmup", type=int, default=30)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,6 +181,9 @@ def main():
     b = uniform(0xB1A6, (n, n), dtype=np.float32)
     da, db, dc = bla.to_device(a), bla.to_device(b), bla.empty((n, n))
     stream = L.bla_default_stream()
+    if dist is not None:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream   # RCCL orders itself against torch's current stream
 
     def step():
         bla.gemm(da, db, dc, stream=stream)
@@ -156,6 +242,12 @@ def main():
         err = np.linalg.norm(got - c_cpu) / np.linalg.norm(c_cpu)
         out["config"]["rel_err_vs_cpu_slice"] = float(f"{err:.3e}")
         assert err < 1e-5, f"GPU result differs from the CPU reference slice: {err}"
+    if args.mnist_steps > 0:
+        sec = run_mnist(bla, dist, world, rank, stream, args.mnist_steps, args.mnist_warmup, barrier)
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                sec["cpu_baseline"] = cpu_baseline_mnist(256)
+            out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -63,6 +63,22 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (file name without version, SONAME
+    libamdhip64.so.7); libbla_hip.so asks for libamdhip64.so.7.  If we are loaded before torch, the dynamic linker
+    would satisfy that from /opt/rocm and a later `import torch` would bring a SECOND runtime into the process
+    (torch then reports no device, and stream handles are not interchangeable).  Loading torch's copy first makes
+    our NEEDED entry resolve to it by SONAME, whichever import order the application uses.  Pure C programs
+    (the drop-in host layer) never see torch and simply use the system runtime."""
+    from .build import torch_lib_dir
+    tl = torch_lib_dir()
+    if tl:
+        try:
+            C.CDLL(os.path.join(tl, "libamdhip64.so"), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The loaded C-ABI library.  Fails loudly when it has not been built: there is no fallback."""
     global _lib
@@ -70,6 +86,7 @@ def lib():
         if not os.path.exists(_SO):
             raise RuntimeError(f"{_SO} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                                "this package has no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(_SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
