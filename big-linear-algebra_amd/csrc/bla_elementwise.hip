@@ -229,6 +229,13 @@ __global__ void __launch_bounds__(kThreads) softmax_rows_kernel(float* __restric
 	for (int j = lane; j < cols; j += 64) row[j] /= sf;
 }
 
+bla_status window_sum(void* stream, const float* m, int count, int len, int stride, float* out) {
+	if (count <= 0) return BLA_OK;
+	hipLaunchKernelGGL(window_sum_kernel, dim3((count + 3) / 4), dim3(kThreads), 0, pick_stream(stream), m, count, len, stride, out);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 static bla_status reduce_common(void* stream, const float* m, size_t n, int what, float* d_out) {
 	bla_status st = require_ready();
 	if (st) return st;

@@ -39,6 +39,8 @@ struct GemmArgs {
 	const float* bias_row; const float* bias_col;
 	float* pre_act; int ld_pre; int act;
 	const float* relu_mask; int ld_mask;
+	float* row_sum_a;              // fused bias gradient: row_sum_a[r] = sum_k op(A)[r][k]   (wsk kernels, A K-contiguous)
+	const float* softmax_y; float softmax_scale; float* softmax_grad;   // fused column softmax + (p - y)*scale (wsk kernels, M <= 32)
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
@@ -449,6 +451,130 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_glds_kernel(GemmArgs p)
 		}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency-bound shapes (few output tiles, long K: the MNIST-NN layers at batch 256, single-image conv
+// products): one workgroup owns ONE 32x32 output tile and its NW waves split K among themselves.  No
+// operand is shared between waves, so fragments go straight from global memory to VGPRs (no LDS, no
+// barrier in the K loop; each wave prefetches PF k-groups ahead), the NW partial accumulators meet in LDS
+// once at the end and are summed in wave order (deterministic), and the epilogue is fused -- no slab
+// kernel, no second launch.  K-contiguous operands load 16 B per lane (row l&31, k-half l>>5),
+// row-contiguous operands four coalesced dwords per lane.
+template <int NW, bool AKC, bool BKC, bool VEC>
+__global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
+	constexpr int PF = 4;  // k-groups (8 k each) in flight per wave
+	__shared__ float red[NW][32 * 33];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+	const int m0 = tile_m * 32, n0 = tile_n * 32;
+	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8
+	const int k_begin = wave * kw, k_end = min(p.K, k_begin + kw);
+	const int arow = min(m0 + l31, p.M - 1), bcol = min(n0 + l31, p.N - 1);  // clamped: out-of-range rows/cols are never stored
+
+	auto load = [&](int k, float (&a)[4], float (&b)[4]) {
+		const int kb = k + 4 * h;
+		if (AKC) {
+			if (VEC) {
+				float4 x = *reinterpret_cast<const float4*>(p.A + (size_t)arow * p.lda + min(kb, p.K - 4));
+				bool ok = kb < k_end;
+				a[0] = ok ? x.x : 0.f; a[1] = ok ? x.y : 0.f; a[2] = ok ? x.z : 0.f; a[3] = ok ? x.w : 0.f;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) { float x = p.A[(size_t)arow * p.lda + min(kb + j, p.K - 1)]; a[j] = kb + j < k_end ? x : 0.f; }
+			}
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) { float x = p.A[(size_t)min(kb + j, p.K - 1) * p.lda + arow]; a[j] = kb + j < k_end ? x : 0.f; }
+		}
+		if (BKC) {
+			if (VEC) {
+				float4 x = *reinterpret_cast<const float4*>(p.B + (size_t)bcol * p.ldb + min(kb, p.K - 4));
+				bool ok = kb < k_end;
+				b[0] = ok ? x.x : 0.f; b[1] = ok ? x.y : 0.f; b[2] = ok ? x.z : 0.f; b[3] = ok ? x.w : 0.f;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++) { float x = p.B[(size_t)bcol * p.ldb + min(kb + j, p.K - 1)]; b[j] = kb + j < k_end ? x : 0.f; }
+			}
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) { float x = p.B[(size_t)min(kb + j, p.K - 1) * p.ldb + bcol]; b[j] = kb + j < k_end ? x : 0.f; }
+		}
+	};
+
+	f32x16 acc;
+#pragma unroll
+	for (int r = 0; r < 16; r++) acc[r] = 0.f;
+	float fa[PF][4], fb[PF][4];
+	float rs = 0.f;   // this lane's share of sum_k A[row][k] (fused bias gradient)
+	const bool want_rs = p.row_sum_a != nullptr && tile_n == 0;
+#pragma unroll
+	for (int g = 0; g < PF; g++) load(k_begin + 8 * g, fa[g], fb[g]);
+	for (int k = k_begin; k < k_end; k += 8 * PF) {
+		float na[PF][4], nb[PF][4];
+#pragma unroll
+		for (int g = 0; g < PF; g++) load(k + 8 * (PF + g), na[g], nb[g]);   // next batch in flight under these MFMAs
+		if (want_rs) {
+#pragma unroll
+			for (int g = 0; g < PF; g++) rs += (fa[g][0] + fa[g][1]) + (fa[g][2] + fa[g][3]);
+		}
+#pragma unroll
+		for (int g = 0; g < PF; g++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
+#pragma unroll
+		for (int g = 0; g < PF; g++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) { fa[g][j] = na[g][j]; fb[g][j] = nb[g][j]; }
+	}
+	// partial tiles -> LDS (stride 33: the C/D map writes 32 consecutive columns per register), sum in wave order
+#pragma unroll
+	for (int r = 0; r < 16; r++) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+	__shared__ float red_rs[NW][64];
+	if (want_rs) red_rs[wave][lane] = rs;
+	__syncthreads();
+	if (want_rs && tid < 32 && m0 + tid < p.M) {
+		float t = 0.f;
+#pragma unroll
+		for (int w = 0; w < NW; w++) t += red_rs[w][tid] + red_rs[w][tid + 32];
+		p.row_sum_a[m0 + tid] = t;
+	}
+	if (p.softmax_grad == nullptr) {
+		for (int e = tid; e < 1024; e += NW * 64) {
+			int r = e >> 5, c = e & 31;
+			float s = 0.f;
+#pragma unroll
+			for (int w = 0; w < NW; w++) s += red[w][r * 33 + c];
+			if (m0 + r < p.M && n0 + c < p.N) epilogue_store(p, m0 + r, n0 + c, s);
+		}
+		return;
+	}
+	// fused tail for the output layer (M <= 32: this tile holds whole columns): Z = alpha*acc + bias -> pre_act,
+	// P = softmax over the rows of each column -> C, grad = (P - Y) * scale        (model/mnist_nn.c:231-234,260-268)
+	for (int e = tid; e < 1024; e += NW * 64) {
+		int r = e >> 5, c = e & 31;
+		float s = 0.f;
+#pragma unroll
+		for (int w = 0; w < NW; w++) s += red[w][r * 33 + c];
+		s *= p.alpha;
+		if (p.bias_row && r < p.M) s += p.bias_row[r];
+		red[0][r * 33 + c] = s;   // element e is read and rewritten by this thread only: no barrier needed here
+		if (p.pre_act && r < p.M && n0 + c < p.N) p.pre_act[(size_t)r * p.ld_pre + n0 + c] = s;
+	}
+	__syncthreads();
+	if (tid < 32 && n0 + tid < p.N) {
+		const int c = tid, col = n0 + tid;
+		float mx = -INFINITY;
+		for (int r = 0; r < p.M; r++) mx = fmaxf(mx, red[0][r * 33 + c]);
+		float sum = 0.f;
+		for (int r = 0; r < p.M; r++) { float e = expf(red[0][r * 33 + c] - mx); red[0][r * 33 + c] = e; sum += e; }
+		for (int r = 0; r < p.M; r++) {
+			float pr = red[0][r * 33 + c] / sum;
+			p.C[(size_t)r * p.ldc + col] = pr;
+			p.softmax_grad[(size_t)r * p.ldc + col] = (pr - p.softmax_y[(size_t)r * p.ldc + col]) * p.softmax_scale;
+		}
+	}
+}
+
 // Sums the split-K slabs in split order (deterministic) and applies the epilogue.
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
 	size_t total = (size_t)p.M * p.N;
@@ -467,6 +593,9 @@ static const Config kConfigs[] = {
 	{128, 128, 16, 256, true, "glds128x128x16"},
 	{64, 64, 16, 256, true, "glds64x64x16"},
 	{128, 128, 32, 256, true, "glds128x128x32"},
+	{32, 32, 8, 256, false, "wsk32x32_w4"},     // wave-split-K, 4 / 8 / 16 waves per 32x32 tile
+	{32, 32, 8, 512, false, "wsk32x32_w8"},
+	{32, 32, 8, 1024, false, "wsk32x32_w16"},
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -523,6 +652,17 @@ static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, 
 #undef BLA_LAUNCH
 }
 
+template <int NW>
+static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
+	dim3 block(NW * 64);
+#define BLA_LAUNCH(AK, BK_, V) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<NW, AK, BK_, V>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
+	if (akc && !bkc) { if (vec) BLA_LAUNCH(true, false, true); else BLA_LAUNCH(true, false, false); }
+	if (akc && bkc) { if (vec) BLA_LAUNCH(true, true, true); else BLA_LAUNCH(true, true, false); }
+	if (!akc && !bkc) BLA_LAUNCH(false, false, false);
+	if (vec) BLA_LAUNCH(false, true, true); else BLA_LAUNCH(false, true, false);
+#undef BLA_LAUNCH
+}
+
 }  // namespace bla
 
 using namespace bla;
@@ -557,6 +697,12 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 	a.bias_row = ep ? ep->bias_row : nullptr; a.bias_col = ep ? ep->bias_col : nullptr;
 	a.pre_act = ep ? ep->pre_act : nullptr; a.ld_pre = ep ? ep->ld_pre : 0; a.act = ep ? ep->act : BLA_ACT_NONE;
 	a.relu_mask = ep ? ep->relu_mask : nullptr; a.ld_mask = ep ? ep->ld_mask : 0;
+	a.row_sum_a = ep ? ep->row_sum_a : nullptr;
+	a.softmax_y = ep ? ep->softmax_y : nullptr; a.softmax_scale = ep ? ep->softmax_scale : 0.f; a.softmax_grad = ep ? ep->softmax_grad : nullptr;
+	BLA_REQUIRE(!a.row_sum_a || !transa, BLA_ERR_INVALID, "row_sum_a needs a non-transposed A");
+	BLA_REQUIRE((a.softmax_y == nullptr) == (a.softmax_grad == nullptr), BLA_ERR_INVALID, "softmax_y and softmax_grad go together");
+	BLA_REQUIRE(!a.softmax_grad || (m <= 32 && a.beta == 0.f && !a.relu_mask && a.act == BLA_ACT_NONE && !a.bias_col && k > 0), BLA_ERR_INVALID,
+	            "fused softmax needs m <= 32, k > 0 and no other post-ops than bias_row/pre_act");
 	BLA_REQUIRE(!a.pre_act || a.ld_pre >= n, BLA_ERR_INVALID, "ld_pre %d < n %d", a.ld_pre, n);
 	BLA_REQUIRE(!a.relu_mask || a.ld_mask >= n, BLA_ERR_INVALID, "ld_mask %d < n %d", a.ld_mask, n);
 
@@ -568,10 +714,29 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 	int cfg = g_force_config;
 	if (cfg < 0) {
 		long big_tiles = (long)((m + 127) / 128) * ((n + 127) / 128);
+		long tiles32 = (long)((m + 31) / 32) * ((n + 31) / 32);
 		bool big = big_tiles >= cus / 2;
-		if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;   // direct-to-LDS fast path
+		if (((!big && tiles32 <= 512) || a.softmax_grad) && k > 0) cfg = k >= 1024 ? 8 : (k >= 512 ? 7 : 6);   // latency-bound: wave-split-K, no slabs
+		else if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;                      // direct-to-LDS fast path
 		else cfg = big ? 0 : 1;
 	}
+	if (cfg >= 6) {   // wave-split-K kernels: one 32x32 tile per workgroup, K divided over its waves
+		BLA_REQUIRE(k > 0, BLA_ERR_INVALID, "gemm config %d needs k > 0", cfg);
+		const int nw = cfg == 6 ? 4 : (cfg == 7 ? 8 : 16);
+		a.tiles_m = (m + 31) / 32; a.tiles_n = (n + 31) / 32;
+		a.k_per_split = ((k + nw - 1) / nw + 7) / 8 * 8;
+		a.splits = 1; a.slab = nullptr;
+		const bool vec = k % 4 == 0 && k >= 4 && (!akc || (lda % 4 == 0 && (uintptr_t)A % 16 == 0)) && (!bkc || (ldb % 4 == 0 && (uintptr_t)B % 16 == 0));
+		dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+		hipError_t e = cfg == 6 ? launch_wsk<4>(a, akc, bkc, vec, grid, s) : cfg == 7 ? launch_wsk<8>(a, akc, bkc, vec, grid, s)
+		                                                                           : launch_wsk<16>(a, akc, bkc, vec, grid, s);
+		if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk_kernel launch");
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n', vec ? "vec" : "scalar");
+		return BLA_OK;
+	}
+	BLA_REQUIRE(!a.softmax_grad || cfg >= 6, BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K configs (6-8)");
+	float* deferred_row_sum = nullptr;   // tiled kernels do not fuse the row sum: run it as a separate pass below
+	if (cfg < 6 && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
 	if (kConfigs[cfg].glds && !(vec_ok && k > 0 && k % kConfigs[cfg].bk == 0)) {
 		set_error("gemm config %d (%s) needs 16-byte aligned operands, contiguous extents %% 4 == 0 and k %% %d == 0", cfg,
 		          kConfigs[cfg].name, kConfigs[cfg].bk);
@@ -632,6 +797,7 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		e = hipGetLastError();
 		if (e != hipSuccess) return hip_fail(e, "gemm_splitk_reduce_kernel launch");
 	}
+	if (deferred_row_sum) return window_sum(stream, A, m, k, lda, deferred_row_sum);
 	return BLA_OK;
 }
 

@@ -24,6 +24,8 @@ bla_status hip_fail(hipError_t e, const char* what);
 bla_status require_ready();
 // Scratch of at least `bytes` (device); valid until the next ensure_workspace call that grows it.
 bla_status ensure_workspace(size_t bytes, void** out);
+// out[i] = sum_{j<len} m[i*stride + j], i < count (bla_elementwise.hip)
+bla_status window_sum(void* stream, const float* m, int count, int len, int stride, float* out);
 inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : ctx().stream; }
 
 #define BLA_HIP(call)                                               \

@@ -153,29 +153,44 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 	float *dW3 = nn->grads + nn->off[4], *db3 = nn->grads + nn->off[5];
 	hipStream_t s = pick_stream(stream);
 
-	// input scale, :218 (1 / 255.0F is a float expression)
-	BLA_HIP(hipMemcpyAsync(nn->x, d_x_raw, (size_t)n0 * B * sizeof(float), hipMemcpyDeviceToDevice, s));
-	st = bla_scale_f32(s, nn->x, (size_t)n0 * B, 1 / 255.0F); if (st) return st;
+	// The input scale of :218 (x *= 1/255.0F, a float expression) is folded into the two products that read X:
+	// W1.(s x) = s (W1.x) and dZ1.(s x)^T = s (dZ1.x^T) -- no pass over the 784 x B input at all.
+	const float xs = 1 / 255.0F;
+	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
 
-	bla_gemm_epilogue ep = {1.f, 0.f, b1, nullptr, nn->z1, B, BLA_ACT_RELU, nullptr, 0};
-	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, nn->x, B, nn->a1, B, &ep); if (st) return st;           // :221-224
-	ep.bias_row = b2; ep.pre_act = nn->z2;
+	bla_gemm_epilogue ep = {};
+	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
+	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, d_x_raw, B, nn->a1, B, &ep); if (st) return st;         // :221-224
+	ep.alpha = 1.f; ep.bias_row = b2; ep.pre_act = nn->z2;
 	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;          // :226-229
+	// output layer: Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) * (1/n0)   (:231-234,260-268;
+	// scale = 1 / (double) LAYER_INPUT_SIZE).  Fused into the product's tail when the layer fits one tile row.
 	ep.bias_row = b3; ep.pre_act = nn->z3; ep.act = BLA_ACT_NONE;
-	st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;          // :231-233
-	// softmax per column, then dZ3 = (A3 - Y) * (1/n0): :234,260-268 (scale = 1 / (double) LAYER_INPUT_SIZE)
-	st = bla_softmax_cols_grad_f32(s, nn->a3, n3, B, d_y, (float)(1 / (double)n0), nn->dz3); if (st) return st;
+	const float gscale = (float)(1 / (double)n0);
+	if (n3 <= 32) {
+		ep.softmax_y = d_y; ep.softmax_scale = gscale; ep.softmax_grad = nn->dz3;
+		st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
+	} else {
+		st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
+		st = bla_softmax_cols_grad_f32(s, nn->a3, n3, B, d_y, gscale, nn->dz3); if (st) return st;
+	}
 
-	st = bla_gemm_f32(s, 0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, nullptr); if (st) return st;    // dW3 = dZ3 . A2^T, :267-270
-	st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st;                           // :271
-	bla_gemm_epilogue em = {1.f, 0.f, nullptr, nullptr, nullptr, 0, BLA_ACT_NONE, nn->z2, B};
+	bla_gemm_epilogue eg = {};
+	eg.alpha = 1.f; eg.row_sum_a = fuse_db ? db3 : nullptr;
+	st = bla_gemm_f32(s, 0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, &eg); if (st) return st;         // dW3 = dZ3 . A2^T, :267-270; db3 :271
+	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st; }
+	bla_gemm_epilogue em = {};
+	em.alpha = 1.f; em.relu_mask = nn->z2; em.ld_mask = B;
 	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st;         // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278
-	st = bla_gemm_f32(s, 0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, nullptr); if (st) return st;    // :279-281
-	st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st;                           // :282
+	eg.row_sum_a = fuse_db ? db2 : nullptr;
+	st = bla_gemm_f32(s, 0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &eg); if (st) return st;         // :279-282
+	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st; }
 	em.relu_mask = nn->z1;
 	st = bla_gemm_f32(s, 1, 0, n1, B, n2, W2, n1, nn->dz2, B, nn->dz1, B, &em); if (st) return st;         // :284-289
-	st = bla_gemm_f32(s, 0, 1, n1, n0, B, nn->dz1, B, nn->x, B, dW1, n0, nullptr); if (st) return st;     // :290-292
-	return bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode);                                            // :293
+	eg.alpha = xs; eg.row_sum_a = fuse_db ? db1 : nullptr;
+	st = bla_gemm_f32(s, 0, 1, n1, n0, B, nn->dz1, B, d_x_raw, B, dW1, n0, &eg); if (st) return st;        // :290-293
+	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode); if (st) return st; }
+	return BLA_OK;
 }
 
 /* params += lr * grads over the whole bucket: the six {clip (no-op at INFINITY), scale, add} triples of :296-315.

@@ -21,7 +21,8 @@ class Epilogue(C.Structure):
     """struct bla_gemm_epilogue (include/bla.h)."""
     _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("bias_row", C.c_void_p), ("bias_col", C.c_void_p),
                 ("pre_act", C.c_void_p), ("ld_pre", C.c_int), ("act", C.c_int), ("relu_mask", C.c_void_p),
-                ("ld_mask", C.c_int)]
+                ("ld_mask", C.c_int), ("row_sum_a", C.c_void_p), ("softmax_y", C.c_void_p), ("softmax_scale", C.c_float),
+                ("softmax_grad", C.c_void_p)]
 
 
 _VP, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -174,7 +175,8 @@ def _ptr(x):
 
 
 def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None, bias_col=None, pre_act=None,
-         act=ACT_NONE, relu_mask=None, stream=None, m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+         act=ACT_NONE, relu_mask=None, stream=None, m=None, n=None, k=None, lda=None, ldb=None, ldc=None,
+         row_sum_a=None, softmax_y=None, softmax_scale=0.0, softmax_grad=None):
     """C = epilogue(alpha * op(A) op(B)) on device arrays; shapes default to the arrays' own."""
     if m is None:
         m = a.shape[1] if transa else a.shape[0]
@@ -186,7 +188,8 @@ def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None
     if isinstance(b, DeviceArray) and kb != k and ldb is None:
         raise BlaError(2, f"inner dimensions differ: {k} vs {kb}")
     ep = Epilogue(alpha, beta, _ptr(bias_row), _ptr(bias_col), _ptr(pre_act), pre_act.ld if pre_act is not None else 0,
-                  act, _ptr(relu_mask), relu_mask.ld if relu_mask is not None else 0)
+                  act, _ptr(relu_mask), relu_mask.ld if relu_mask is not None else 0, _ptr(row_sum_a), _ptr(softmax_y),
+                  softmax_scale, _ptr(softmax_grad))
     check(lib().bla_gemm_f32(stream, int(transa), int(transb), m, n, k, _ptr(a), lda or a.ld, _ptr(b), ldb or b.ld,
                              _ptr(c), ldc or c.ld, C.byref(ep)))
     return c

@@ -89,6 +89,7 @@ BLA_API bla_status bla_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms
  *   act == BLA_ACT_RELU: v = v < 0 ? 0 : v        (lib/util.c:7-13)
  *   relu_mask: v *= (relu_mask[r*ld_mask + c] > 0 ? 1 : 0)   (relu_ddx + hadamard, model/mnist_nn.c:276-278)
  *   beta != 0: v += beta * C[r*ldc + c]
+ * A NULL epilogue means alpha = 1 and nothing else.  When passing a struct, zero-initialise it and set alpha.
  */
 enum { BLA_ACT_NONE = 0, BLA_ACT_RELU = 1 };
 
@@ -102,6 +103,15 @@ typedef struct bla_gemm_epilogue {
 	int act;                   /* BLA_ACT_* */
 	const float* relu_mask;    /* device m x n (ld_mask), or NULL */
 	int ld_mask;
+	/* by-products fused into the latency-bound kernels (run as separate passes elsewhere):
+	 *   row_sum_a[r] = sum_k A[r][k] (needs !transa): with A = dZ this is the bias gradient "sum over the batch
+	 *   columns", the documented intent of matrix_col_sum (model/mnist_nn.c:271,282,293);
+	 *   softmax_y/softmax_grad (m <= 32, no other post-op than bias_row/pre_act): C = column softmax of the result,
+	 *   softmax_grad = (C - softmax_y) * softmax_scale, both with leading dimension ldc (model/mnist_nn.c:234,260-268). */
+	float* row_sum_a;
+	const float* softmax_y;
+	float softmax_scale;
+	float* softmax_grad;
 } bla_gemm_epilogue;
 
 BLA_API bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,

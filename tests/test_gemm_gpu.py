@@ -59,14 +59,15 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
-    Configs 3-5 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0."""
+    Configs 3-5 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0.
+    Configs 6-8 are the wave-split-K kernels for latency-bound shapes (any shape, k > 0)."""
     dev.lib().bla_gemm_set_config(cfg, 0)
     shapes = [(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128), (257, 100, 31), (200, 260, 136)]
-    if cfg >= 3:
+    if 3 <= cfg <= 5:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
                   (384, 512, 256)]
     try:
@@ -159,3 +160,39 @@ def test_large_square_sampled_rows(dev, ora, n):
     assert np.array_equal(dev.gemm(da, eye, dc).numpy(), a)                 # products with 0/1 are exact
     c2 = dev.gemm(da, db, dc, alpha=2.0).numpy()
     assert np.array_equal(c2, 2 * c)                                         # power-of-two scaling is exact
+
+
+@pytest.mark.parametrize("cfg", [-1, 1, 4, 6, 7, 8])
+def test_fused_row_sum_of_a(dev, ora, cfg):
+    """row_sum_a[r] = sum_k A[r][k] rides along the product (bias gradient = true row sums of dZ, the intent of
+    matrix_col_sum, model/mnist_nn.c:271): fused in the wave-split-K kernels, a separate pass behind the tiled ones."""
+    dev.lib().bla_gemm_set_config(cfg, 0)
+    try:
+        for (m, k, n) in [(10, 256, 128), (128, 256, 256), (70, 96, 40)]:
+            a = uniform(31, (m, k), dtype=np.float32); b = uniform(32, (n, k), dtype=np.float32)
+            rs = dev.empty((m,)).fill_bytes(0xFF); c = dev.empty((m, n))
+            dev.gemm(dev.to_device(a), dev.to_device(b), c, transb=True, row_sum_a=rs)
+            check_gemm(ora, c.numpy(), a, b.T, tag=f"cfg{cfg} {m}x{k}x{n}")
+            want = ora.col_sum_intended(a.astype(np.float64)).ravel()
+            assert (np.abs(rs.numpy() - want) <= 2e-6 * np.abs(a).sum(1)).all()
+    finally:
+        dev.lib().bla_gemm_set_config(-1, 0)
+
+
+def test_fused_softmax_tail(dev, ora):
+    """Output layer in one launch: Z = W A + b (kept), P = softmax per column, grad = (P - Y) * scale
+    (model/mnist_nn.c:231-234,260-268)."""
+    m, k, n = 10, 128, 300
+    w = uniform(41, (m, k), dtype=np.float32); x = uniform(42, (k, n), -2, 2, np.float32); b = uniform(43, (m, 1), dtype=np.float32)
+    y = np.zeros((m, n), np.float32); y[np.arange(n) % m, np.arange(n)] = 1
+    z, p, g = dev.empty((m, n)), dev.empty((m, n)), dev.empty((m, n))
+    dev.gemm(dev.to_device(w), dev.to_device(x), p, bias_row=dev.to_device(b), pre_act=z, softmax_y=dev.to_device(y),
+             softmax_scale=1 / 784, softmax_grad=g)
+    z64 = ora.add_tile_columns(ora.matmul(w.astype(np.float64), x.astype(np.float64)), b.astype(np.float64))
+    bound = np.abs(w.astype(np.float64)) @ np.abs(x.astype(np.float64)) + np.abs(b)
+    assert (np.abs(z.numpy() - z64) <= 1e-5 * bound).all()
+    p64 = ora.softmax_cols(z64)
+    assert np.allclose(p.numpy(), p64, rtol=1e-4, atol=1e-7)
+    assert np.allclose(g.numpy(), (p64 - y) / 784, rtol=1e-4, atol=1e-9)
+    with pytest.raises(dev.BlaError):     # m > 32 cannot hold whole columns in one tile
+        dev.gemm(dev.zeros((40, 8)), dev.zeros((8, 8)), dev.zeros((40, 8)), softmax_y=dev.zeros((40, 8)), softmax_grad=dev.zeros((40, 8)))
