@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_f32_glds_kernel(GemmArgs p)
 // row-contiguous operands four coalesced dwords per lane.
 template <int NW, bool AKC, bool BKC, bool VEC>
 __global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
-	constexpr int PF = 4;  // k-groups (8 k each) in flight per wave
+	constexpr int PF = 8;  // k-groups (8 k each) per chunk = 64 k: all loads of a chunk are in flight together
 	__shared__ float red[NW][32 * 33];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l31 = lane & 31, h = lane >> 5;
@@ -504,15 +504,15 @@ __global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
 	f32x16 acc;
 #pragma unroll
 	for (int r = 0; r < 16; r++) acc[r] = 0.f;
-	float fa[PF][4], fb[PF][4];
 	float rs = 0.f;   // this lane's share of sum_k A[row][k] (fused bias gradient)
 	const bool want_rs = p.row_sum_a != nullptr && tile_n == 0;
-#pragma unroll
-	for (int g = 0; g < PF; g++) load(k_begin + 8 * g, fa[g], fb[g]);
+	// Chunks of PF k-groups: ALL of a chunk's loads are issued before its first MFMA (maximum memory-level
+	// parallelism: these shapes are latency-bound), then the MFMAs consume them in order behind counted waits.
+	// The launcher sizes the wave count so that a wave's whole K extent is one chunk whenever K <= 64 * 16.
 	for (int k = k_begin; k < k_end; k += 8 * PF) {
-		float na[PF][4], nb[PF][4];
+		float fa[PF][4], fb[PF][4];
 #pragma unroll
-		for (int g = 0; g < PF; g++) load(k + 8 * (PF + g), na[g], nb[g]);   // next batch in flight under these MFMAs
+		for (int g = 0; g < PF; g++) load(k + 8 * g, fa[g], fb[g]);
 		if (want_rs) {
 #pragma unroll
 			for (int g = 0; g < PF; g++) rs += (fa[g][0] + fa[g][1]) + (fa[g][2] + fa[g][3]);
@@ -521,10 +521,6 @@ __global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
 		for (int g = 0; g < PF; g++)
 #pragma unroll
 			for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
-#pragma unroll
-		for (int g = 0; g < PF; g++)
-#pragma unroll
-			for (int j = 0; j < 4; j++) { fa[g][j] = na[g][j]; fb[g][j] = nb[g][j]; }
 	}
 	// partial tiles -> LDS (stride 33: the C/D map writes 32 consecutive columns per register), sum in wave order
 #pragma unroll
@@ -716,7 +712,10 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		long big_tiles = (long)((m + 127) / 128) * ((n + 127) / 128);
 		long tiles32 = (long)((m + 31) / 32) * ((n + 31) / 32);
 		bool big = big_tiles >= cus / 2;
-		if (((!big && tiles32 <= 512) || a.softmax_grad) && k > 0) cfg = k >= 1024 ? 8 : (k >= 512 ? 7 : 6);   // latency-bound: wave-split-K, no slabs
+		// Latency-bound shapes: one 32x32 tile per workgroup, K split over its 4 waves (one per SIMD), no slabs.
+		// A CU retires 256 fp32 MFMA FLOP/clk whatever the wave count (measured: 8 or 16 waves per tile only add
+		// overhead), so a tile costs ~8*K cycles; beyond K ~ 1024 splitting K over workgroups (tiled path) wins.
+		if (((!big && tiles32 <= 512 && k <= 1280) || a.softmax_grad) && k > 0) cfg = 6;
 		else if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;                      // direct-to-LDS fast path
 		else cfg = big ? 0 : 1;
 	}
