@@ -234,6 +234,15 @@ def main():
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": 3 * n * n * 4},
     }
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (it cannot be collected from
+    # inside this process); the committed summary applies when it was taken on this exact kernel and size
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm4096_traffic.json")))
+        if n == 4096 and tr["kernel"] == out["config"]["kernel"]:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_gemm4096_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, c_cpu, rows = cpu_baseline_gemm(n)
         out["cpu_baseline"] = base
