@@ -171,6 +171,193 @@ static inline unsigned grid_for(size_t n) {
 	return (unsigned)b;
 }
 
+// ---- implicit-GEMM convolution ---------------------------------------------------------------------------
+// The im2col matrix is never materialised: the MFMA kernel gathers it from the [C][H][W] image while it loads its
+// B operand.  Same skeleton as the wave-split-K GEMM (bla_gemm.hip): one workgroup per 32x32 output tile, its 4 waves
+// split K, fragments go global -> VGPR (the image is L2-resident), partials meet in LDS.
+//   FWD   : out[F][Ho*Wo]   = kern[F][K]    . G[K][Ho*Wo],  K = C*k*k,  G[(c,p,q)][(i,j)] = x[c][i*s+p-pt][j*s+q-pl]
+//           lanes run over consecutive output pixels -> consecutive image addresses (coalesced), zero outside.
+//           The data gradient of a stride-1 conv is the same contraction with the kernels transposed and
+//           flipped and del_Y as the image, so it reuses this mode (no del_col matrix, no col2im).
+//   WGRAD : dkern[F][K]     = del_y[F][HW]  . G^T[HW][K]        (= _reshape_matrix_kernels(im2col^T . del_Q))
+// A per-geometry table (built once on the device, cached) maps k -> {image offset of tap (c,p,q), dy, dx}.
+struct ConvGeom { int h, w, k, c, s, ho, wo, pt, pl; };
+struct ConvArgs {
+	const float* A; int lda;     // FWD: kernels [F][K]; WGRAD: del_y [F][HW]
+	const float* img;            // [C][H][W]
+	const int2* tab;             // [C*k*k] {offset, dy | dx << 16}
+	float* out; int ldo;
+	int M, N, K;                 // output M x N, contraction K
+	int tiles_n, kw;             // kw: K extent per wave (multiple of 8)
+	int splits, k_per_split;     // K is also cut over blockIdx.y; partial products go to slab[split][M][N]
+	float* slab;
+	ConvGeom g;
+};
+
+enum { CONV_FWD = 0, CONV_WGRAD = 1 };
+
+__global__ void __launch_bounds__(256) conv_table_kernel(int2* tab, ConvGeom g) {
+	int kidx = blockIdx.x * blockDim.x + threadIdx.x;
+	int kk = g.k * g.k;
+	if (kidx >= g.c * kk) return;
+	int c = kidx / kk, p = (kidx % kk) / g.k, q = kidx % g.k;
+	int dy = p - g.pt, dx = q - g.pl;
+	tab[kidx] = make_int2(c * g.h * g.w + dy * g.w + dx, (dy & 0xffff) | (dx << 16));
+}
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
+	constexpr int NW = 4, PF = 8;
+	typedef float f32x16 __attribute__((ext_vector_type(16)));
+	__shared__ float red[NW][32 * 33];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l31 = lane & 31, h = lane >> 5;
+	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+	const int m0 = tile_m * 32, n0 = tile_n * 32;
+	const int split_end = min(p.K, (int)(blockIdx.y + 1) * p.k_per_split);
+	const int k_begin = min(split_end, (int)blockIdx.y * p.k_per_split + wave * p.kw), k_end = min(split_end, k_begin + p.kw);
+	const int arow = min(m0 + l31, p.M - 1);
+	const int ncol = min(n0 + l31, p.N - 1);
+	const ConvGeom g = p.g;
+	// lane-invariant part of the gather
+	int base, y0, x0;
+	if (MODE == CONV_FWD) {          // n = output pixel (i, j)
+		int i = ncol / g.wo, j = ncol - i * g.wo;
+		y0 = i * g.s; x0 = j * g.s; base = y0 * g.w + x0;
+	} else {                         // n = tap (c, p, q)
+		int2 t = p.tab[ncol];
+		base = t.x; y0 = (short)(t.y & 0xffff); x0 = t.y >> 16;
+	}
+
+	auto load = [&](int k, float (&a)[4], float (&b)[4]) {
+		const int kb = k + 4 * h;
+		if (VEC) {
+			float4 x = *reinterpret_cast<const float4*>(p.A + (size_t)arow * p.lda + min(kb, p.K - 4));
+			bool ok = kb < k_end;
+			a[0] = ok ? x.x : 0.f; a[1] = ok ? x.y : 0.f; a[2] = ok ? x.z : 0.f; a[3] = ok ? x.w : 0.f;
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) { float x = p.A[(size_t)arow * p.lda + min(kb + j, p.K - 1)]; a[j] = kb + j < k_end ? x : 0.f; }
+		}
+		if (MODE == CONV_FWD) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				int2 t = p.tab[min(kb + j, p.K - 1)];
+				int yy = y0 + (short)(t.y & 0xffff), xx = x0 + (t.y >> 16);
+				bool ok = kb + j < k_end && (unsigned)yy < (unsigned)g.h && (unsigned)xx < (unsigned)g.w;
+				float v = p.img[ok ? t.x + base : 0];
+				b[j] = ok ? v : 0.f;
+			}
+		} else {   // k = output pixel r = (i, j): one division per group, then walk
+			int r = min(kb, p.K - 1);
+			int i = r / g.wo, j = r - i * g.wo;
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				int yy = i * g.s + y0, xx = j * g.s + x0;
+				bool ok = kb + e < k_end && (unsigned)yy < (unsigned)g.h && (unsigned)xx < (unsigned)g.w;
+				float v = p.img[ok ? base + i * g.s * g.w + j * g.s : 0];
+				b[e] = ok ? v : 0.f;
+				if (++j == g.wo) { j = 0; i++; }
+			}
+		}
+	};
+
+	f32x16 acc;
+#pragma unroll
+	for (int r = 0; r < 16; r++) acc[r] = 0.f;
+	for (int k = k_begin; k < k_end; k += 8 * PF) {
+		float fa[PF][4], fb[PF][4];
+#pragma unroll
+		for (int gidx = 0; gidx < PF; gidx++) load(k + 8 * gidx, fa[gidx], fb[gidx]);
+#pragma unroll
+		for (int gidx = 0; gidx < PF; gidx++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx][j], fb[gidx][j], acc, 0, 0, 0);
+	}
+#pragma unroll
+	for (int r = 0; r < 16; r++) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+	__syncthreads();
+	for (int e = tid; e < 1024; e += NW * 64) {
+		int r = e >> 5, c = e & 31;
+		float s = (red[0][r * 33 + c] + red[1][r * 33 + c]) + (red[2][r * 33 + c] + red[3][r * 33 + c]);
+		if (m0 + r < p.M && n0 + c < p.N) {
+			if (p.splits > 1) p.slab[((size_t)blockIdx.y * p.M + m0 + r) * p.N + n0 + c] = s;
+			else p.out[(size_t)(m0 + r) * p.ldo + n0 + c] = s;
+		}
+	}
+}
+
+// folds the K-split slabs in split order (deterministic)
+__global__ void __launch_bounds__(kThreads) conv_slab_reduce_kernel(ConvArgs p) {
+	size_t total = (size_t)p.M * p.N;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		float s = 0.f;
+		for (int z = 0; z < p.splits; z++) s += p.slab[(size_t)z * total + i];
+		p.out[(i / p.N) * p.ldo + i % p.N] = s;
+	}
+}
+
+// kt[c][f][p][q] = kern[f][c][k-1-p][k-1-q]: the kernels of the data-gradient convolution
+__global__ void __launch_bounds__(kThreads) flip_kernels_kernel(const float* __restrict__ kern, float* __restrict__ kt, int f_n, int c_n, int k) {
+	int kk = k * k, total = f_n * c_n * kk;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		int pq = e % kk, f = (e / kk) % f_n, c = e / (kk * f_n);
+		int p = pq / k, q = pq % k;
+		kt[e] = kern[((size_t)f * c_n + c) * kk + (k - 1 - p) * k + (k - 1 - q)];
+	}
+}
+
+// per-geometry gather tables, built once (device memory is never freed: a handful of KB per distinct layer shape)
+struct TableEntry { ConvGeom g; int2* tab; };
+static TableEntry g_tables[64];
+static int g_num_tables = 0;
+
+static bla_status get_table(hipStream_t s, const ConvGeom& g, const int2** out) {
+	for (int i = 0; i < g_num_tables; i++) {
+		const ConvGeom& t = g_tables[i].g;
+		if (t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c && t.s == g.s && t.pt == g.pt && t.pl == g.pl) { *out = g_tables[i].tab; return BLA_OK; }
+	}
+	BLA_REQUIRE(g_num_tables < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	int n = g.c * g.k * g.k;
+	int2* tab;
+	BLA_HIP(hipMalloc((void**)&tab, (size_t)n * sizeof(int2)));
+	hipLaunchKernelGGL(conv_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, g);
+	BLA_HIP(hipGetLastError());
+	g_tables[g_num_tables].g = g; g_tables[g_num_tables].tab = tab; g_num_tables++;
+	*out = tab;
+	return BLA_OK;
+}
+
+template <int MODE>
+static bla_status launch_implicit(hipStream_t s, ConvArgs& a) {
+	a.tiles_n = (a.N + 31) / 32;
+	int tiles = ((a.M + 31) / 32) * a.tiles_n;
+	// long contractions over few tiles are latency-bound: cut K over workgroups until ~3 of them sit on every CU,
+	// keeping >= 128 k per workgroup
+	int splits = (768 + tiles - 1) / tiles;
+	if (splits > a.K / 128) splits = a.K / 128;
+	if (splits < 1) splits = 1;
+	if (splits > 32) splits = 32;
+	a.k_per_split = ((a.K + splits - 1) / splits + 31) / 32 * 32;
+	splits = (a.K + a.k_per_split - 1) / a.k_per_split;
+	a.splits = splits;
+	a.kw = a.k_per_split / 4;   // multiple of 8
+	a.slab = nullptr;
+	if (splits > 1) {
+		void* ws;
+		bla_status st = ensure_workspace((size_t)splits * a.M * a.N * sizeof(float), &ws);
+		if (st) return st;
+		a.slab = (float*)ws;
+	}
+	dim3 grid((unsigned)tiles, (unsigned)splits);
+	bool vec = a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0;
+	if (vec) hipLaunchKernelGGL((conv_implicit_kernel<MODE, true>), grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL((conv_implicit_kernel<MODE, false>), grid, dim3(256), 0, s, a);
+	if (splits > 1) hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(grid_for((size_t)a.M * a.N)), dim3(kThreads), 0, s, a);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 }  // namespace bla
 
 using namespace bla;
@@ -273,6 +460,68 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
 	st = bla_gemm_f32(stream, 0, 1, hw, kkc, f_n, d_del_q, f_n, d_kmat, f_n, d_del_col, kkc, nullptr);
 	if (st) return st;
 	return bla_col2im_f32(stream, d_del_col, d_del_x, h, w, k, c_in, 1);                      // lib/conv.c:228
+}
+
+/* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
+ * same values as conv()'s `output` (lib/conv.c:205-212, intended composition), any stride. */
+bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
+	BLA_REQUIRE(d_x && d_kern && d_out, BLA_ERR_INVALID, "null operand");
+	hipStream_t s = pick_stream(stream);
+	Geometry gm = same_geometry(h, w, k, stride);
+	ConvArgs a;
+	a.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
+	st = get_table(s, a.g, &a.tab);
+	if (st) return st;
+	a.A = d_kern; a.lda = k * k * c_in; a.img = d_x; a.out = d_out; a.ldo = gm.ho * gm.wo;
+	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
+	return launch_implicit<CONV_FWD>(s, a);
+}
+
+/* Gradients of the same convolution (conv_ddx, lib/conv.c:214-229, intended composition) without del_Q / del_col:
+ *   d_del_kern [F][C][k][k] = sum over output pixels of del_y x patches     (any stride)
+ *   d_del_x    [C][H][W]    = conv(del_y, kernels transposed + flipped)     (stride 1 only, as in the reference)
+ * Either output may be NULL.  d_scratch holds the flipped kernels (F*C*k*k floats) when d_del_x is requested. */
+bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
+                                   float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
+	BLA_REQUIRE(d_del_y, BLA_ERR_INVALID, "null operand");
+	hipStream_t s = pick_stream(stream);
+	Geometry gm = same_geometry(h, w, k, stride);
+	if (d_del_kern) {
+		BLA_REQUIRE(d_x, BLA_ERR_INVALID, "weight gradient needs the forward input");
+		ConvArgs a;
+		a.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
+		st = get_table(s, a.g, &a.tab);
+		if (st) return st;
+		a.A = d_del_y; a.lda = gm.ho * gm.wo; a.img = d_x; a.out = d_del_kern; a.ldo = k * k * c_in;
+		a.M = f_n; a.N = k * k * c_in; a.K = gm.ho * gm.wo;
+		st = launch_implicit<CONV_WGRAD>(s, a);
+		if (st) return st;
+	}
+	if (d_del_x) {
+		if (stride != 1) {
+			set_error("the data gradient is undefined in the reference for stride %d (_col2im, lib/conv.c:80-135)", stride);
+			return BLA_ERR_UNDEFINED;
+		}
+		BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
+		int total = f_n * c_in * k * k;
+		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+		BLA_HIP(hipGetLastError());
+		ConvArgs a;   // image = del_y [F][H][W], "input channels" = F, pads mirrored: k-1-pt, k-1-pl
+		a.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
+		st = get_table(s, a.g, &a.tab);
+		if (st) return st;
+		a.A = d_scratch; a.lda = k * k * f_n; a.img = d_del_y; a.out = d_del_x; a.ldo = h * w;
+		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
+		st = launch_implicit<CONV_FWD>(s, a);
+		if (st) return st;
+	}
+	return BLA_OK;
 }
 
 bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw) {

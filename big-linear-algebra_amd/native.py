@@ -53,6 +53,7 @@ SIGNATURES = {
     "bla_kernels_to_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]), "bla_matrix_to_kernels_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]),
     "bla_reshape_channels_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I]), "bla_reshape_matrix_channels_f32": (_I, [_VP, _VP, _VP, _I, _I]),
     "bla_conv_forward_f32": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f32": (_I, [_VP] * 9 + [_I] * 6),
+    "bla_conv2d_forward_f32": (_I, [_VP] * 4 + [_I] * 6), "bla_conv2d_backward_f32": (_I, [_VP] * 7 + [_I] * 6),
     "bla_group_norm_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f32": (_I, [_VP] * 6 + [_I] * 3),
     "bla_mnist_nn_create": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_mnist_nn_destroy": (_I, [_VP]),
     "bla_mnist_nn_param_count": (_SZ, [_VP]), "bla_mnist_nn_params": (_VP, [_VP]), "bla_mnist_nn_grads": (_VP, [_VP]),

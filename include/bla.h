@@ -169,6 +169,13 @@ BLA_API bla_status bla_conv_forward_f32(void* stream, const float* d_x, const fl
 BLA_API bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float* d_im2col, const float* d_kmat, float* d_del_q,
                                          float* d_del_kmat, float* d_del_kern, float* d_del_col, float* d_del_x, int h, int w, int k, int c_in,
                                          int f_n, int stride);
+/* Implicit-GEMM convolution for device-resident callers: the im2col matrix is gathered inside the MFMA kernel and
+ * never written (no ConvData workspaces).  Values equal conv()'s `output` / conv_ddx()'s del_kernels and del_input
+ * (lib/conv.c:205-229, intended composition).  Forward and weight gradient accept any stride; the data gradient is
+ * stride-1 only, like the reference.  d_scratch: F*C*k*k floats, needed only when d_del_x != NULL. */
+BLA_API bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride);
+BLA_API bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern,
+                                           float* d_del_x, float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride);
 /* group_norm / group_norm_ddx, lib/norm.c:5-93, on [C][H*W]; quirk Q3 kept (epsilon == 0, "stdevs" holds the variance,
  * out = (x - mean) / variance).  Note the reference's argument orders (lib/norm.h:6-7). */
 BLA_API bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw);

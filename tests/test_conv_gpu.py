@@ -118,3 +118,39 @@ def test_group_norm(dev, ora):
     call(dev, "bla_group_norm_f32", dev.to_device(np.arange(1, 9, dtype=F32).reshape(2, 2, 2)), out, sd, mu, 2, 32, 4)
     assert mu.numpy()[0] == 4.5 and sd.numpy()[0] == 5.25 and abs(out.numpy().ravel()[0] + 0.6667) < 1e-4
     assert np.allclose(out.numpy(), g["probe_out"], rtol=1e-6)
+
+
+def test_implicit_gemm_conv_matches_reference(dev, ora):
+    """bla_conv2d_forward/backward (im2col gathered inside the MFMA kernel, nothing materialised) against the same
+    golden vectors as the staged path: conv()'s output for every stride, conv_ddx()'s del_kernels / del_input at stride 1,
+    and the weight gradient against the oracle at stride 2 (where the reference's own conv_ddx is undefined)."""
+    g = golden("conv")
+    for i, cfg in enumerate(g["cfgs"]):
+        h, w, cin, cout, k, s, seed, x, kern = conv_case(i, cfg)
+        ho, wo = ora.out_hw(h, w, s)
+        out = dev.empty((cout, ho, wo)).fill_bytes(0xFF)
+        dx_, dk_ = dev.to_device(x), dev.to_device(kern)
+        call(dev, "bla_conv2d_forward_f32", dx_, dk_, out, h, w, k, cin, cout, s)
+        fw = ora.conv_intended(x.astype(np.float64), kern.astype(np.float64), s)
+        bound = (np.abs(fw["im2col"]) @ np.abs(fw["kmat"])).T.reshape(cout, ho, wo)
+        assert (np.abs(out.numpy() - fw["output"]) <= 1e-5 * bound + 1e-30).all(), cfg
+        g.check(f"c{i}_output", out.numpy(), rtol=0, atol=1e-5 * bound.max())
+        del_y = uniform(seed + 3, (cout, ho, wo), -1, 1, F32)
+        dkern = dev.empty((cout, cin, k, k)).fill_bytes(0xFF)
+        if s == 1:
+            dxx = dev.empty((cin, h, w)).fill_bytes(0xFF); scratch = dev.empty((cout * cin * k * k,))
+            call(dev, "bla_conv2d_backward_f32", dev.to_device(del_y), dx_, dk_, dkern, dxx, scratch, h, w, k, cin, cout, 1)
+            dd = ora.conv_ddx_intended(del_y.astype(np.float64), fw["im2col"], fw["kmat"], cin, k)
+            b1 = (np.abs(fw["im2col"]).T @ np.abs(dd["del_q"])).max()
+            g.check(f"c{i}_ddx_del_kern", dkern.numpy(), rtol=0, atol=1e-5 * b1)
+            b2 = (np.abs(dd["del_q"]) @ np.abs(fw["kmat"]).T).max() * k * k
+            g.check(f"c{i}_ddx_del_x", dxx.numpy(), rtol=0, atol=1e-5 * b2)
+        else:
+            call(dev, "bla_conv2d_backward_f32", dev.to_device(del_y), dx_, dk_, dkern, None, None, h, w, k, cin, cout, s)
+            dq = ora.reshape_matrix_channels(del_y.astype(np.float64))                      # [HoWo][F]
+            want = ora.matrix_to_kernels(ora.matmul(ora.transpose(fw["im2col"]), dq), cin, k)   # lib/conv.c:221-223
+            b1 = (np.abs(fw["im2col"]).T @ np.abs(dq)).max()
+            assert (np.abs(dkern.numpy() - want) <= 1e-5 * b1).all()
+            keep = dev.empty((cin, h, w))
+            assert dev.lib().bla_conv2d_backward_f32(None, dev.to_device(del_y).ptr, dx_.ptr, dk_.ptr, None, keep.ptr, keep.ptr,
+                                                     h, w, k, cin, cout, s) == 5                # data gradient: undefined (Q5)
