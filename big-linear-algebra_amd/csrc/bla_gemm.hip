@@ -257,8 +257,10 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 	__device__ static __forceinline__ int off(int r, int c) { return r * BK + swz(r, c) * 4; }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
-__global__ void __launch_bounds__(WM * WN * 64) gemm_f32_glds_kernel(GemmArgs p) {
+// (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
+// at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1>
+__global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	constexpr int NW = WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
@@ -627,13 +629,13 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode
 #undef BLA_LAUNCH
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1>
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 	size_t lds_bytes = 2 * (BM + BN) * BK * sizeof(float);
 	dim3 block(WM * WN * 64);
 #define BLA_LAUNCH(AK, BK_)                                                                                 \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_>;                                      \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW>;                                \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -716,10 +718,12 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		// A CU retires 256 fp32 MFMA FLOP/clk whatever the wave count (measured: 8 or 16 waves per tile only add
 		// overhead), so a tile costs ~8*K cycles; beyond K ~ 1024 splitting K over workgroups (tiled path) wins.
 		if (((!big && tiles32 <= 512 && k <= 1280) || a.softmax_grad) && k > 0) cfg = 6;
-		else if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;                      // direct-to-LDS fast path
+		else if (big && akc && bkc && vec_ok && k % 32 == 0) cfg = 2;   // NT (both operands K-contiguous): measured 130 vs 117 TFLOP/s
+		                                                                  // on 4096^3 for the register-staged BK=32 kernel vs the DMA one
+		else if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;     // direct-to-LDS fast path
 		else cfg = big ? 0 : 1;
 	}
-	if (cfg >= 6) {   // wave-split-K kernels: one 32x32 tile per workgroup, K divided over its waves
+	if (cfg >= 6 && cfg <= 8) {   // wave-split-K kernels: one 32x32 tile per workgroup, K divided over its waves
 		BLA_REQUIRE(k > 0, BLA_ERR_INVALID, "gemm config %d needs k > 0", cfg);
 		const int nw = cfg == 6 ? 4 : (cfg == 7 ? 8 : 16);
 		a.tiles_m = (m + 31) / 32; a.tiles_n = (n + 31) / 32;
@@ -733,9 +737,9 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n', vec ? "vec" : "scalar");
 		return BLA_OK;
 	}
-	BLA_REQUIRE(!a.softmax_grad || cfg >= 6, BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K configs (6-8)");
+	BLA_REQUIRE(!a.softmax_grad || (cfg >= 6 && cfg <= 8), BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K configs (6-8)");
 	float* deferred_row_sum = nullptr;   // tiled kernels do not fuse the row sum: run it as a separate pass below
-	if (cfg < 6 && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
+	if ((cfg < 6 || cfg > 8) && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
 	if (kConfigs[cfg].glds && !(vec_ok && k > 0 && k % kConfigs[cfg].bk == 0)) {
 		set_error("gemm config %d (%s) needs 16-byte aligned operands, contiguous extents %% 4 == 0 and k %% %d == 0", cfg,
 		          kConfigs[cfg].name, kConfigs[cfg].bk);
