@@ -594,6 +594,7 @@ static const Config kConfigs[] = {
 	{32, 32, 8, 256, false, "wsk32x32_w4"},     // wave-split-K, 4 / 8 / 16 waves per 32x32 tile
 	{32, 32, 8, 512, false, "wsk32x32_w8"},
 	{32, 32, 8, 1024, false, "wsk32x32_w16"},
+	{128, 64, 16, 256, true, "glds128x64x16"},
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -720,7 +721,10 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		if (((!big && tiles32 <= 512 && k <= 1280) || a.softmax_grad) && k > 0) cfg = 6;
 		else if (big && akc && bkc && vec_ok && k % 32 == 0) cfg = 2;   // NT (both operands K-contiguous): measured 130 vs 117 TFLOP/s
 		                                                                  // on 4096^3 for the register-staged BK=32 kernel vs the DMA one
-		else if (vec_ok && k % 16 == 0 && k > 0) cfg = big ? 3 : 4;     // direct-to-LDS fast path
+		else if (vec_ok && k % 16 == 0 && k > 0) {                      // direct-to-LDS fast path; tile by how many tiles the chip gets:
+			long t128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);   // 128x128 once there are >= 2 per CU, 128x64 when that still gives
+			cfg = big_tiles >= 2 * cus ? 3 : (t128x64 >= cus ? 9 : 4);  // >= 1 per CU (2048^3: 132 vs 122 TFLOP/s), else 64x64
+		}
 		else cfg = big ? 0 : 1;
 	}
 	if (cfg >= 6 && cfg <= 8) {   // wave-split-K kernels: one 32x32 tile per workgroup, K divided over its waves
@@ -786,7 +790,8 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		case 2: e = launch_variant<128, 128, 32, 2, 2>(a, akc, bkc, mode, grid, s); break;
 		case 3: e = launch_glds<128, 128, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 4: e = launch_glds<64, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
+		case 5: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
