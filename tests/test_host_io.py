@@ -1,0 +1,127 @@
+"""Host-side I/O units of the drop-in layer (csv, mnist_csv2, cifar10, bmp): same bytes / same values / same rand()
+consumption as the reference's units, compared directly against the reference compiled into a scratch .so (only where
+/root/reference exists), plus fixture-free known answers (data/a.csv values)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+LIB = os.path.join(ROOT, "big-linear-algebra_amd", "lib")
+REF = "/root/reference"
+libc = C.CDLL(None)
+
+
+@pytest.fixture(scope="module")
+def ours(pkg):
+    pkg.build_native()
+    L = C.CDLL(os.path.join(LIB, "libbla_host.so"))
+    L.read_csv_contents.restype = C.POINTER(C.c_float)
+    return L
+
+
+@pytest.fixture(scope="module")
+def theirs(tmp_path_factory):
+    if not os.path.isdir(REF):
+        pytest.skip("reference sources only exist in the build container")
+    so = str(tmp_path_factory.mktemp("refio") / "librefio.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-w", "-fPIC", "-shared", "-o", so] +
+                          [os.path.join(REF, "lib", f) for f in ("csv.c", "mnist_csv2.c", "cifar10.c", "bmp.c")] + ["-lm"])
+    L = C.CDLL(so)
+    L.read_csv_contents.restype = C.POINTER(C.c_float)
+    return L
+
+
+def test_csv_roundtrip_and_known_answer(ours, tmp_path):
+    p = str(tmp_path / "a.csv")
+    open(p, "w").write("1,2.3,3,\n4,509,6,\n7,8,9.0,")          # data/a.csv layout: every value comma-terminated
+    v = np.ctypeslib.as_array(ours.read_csv_contents(p.encode()), shape=(9,)).copy()
+    assert np.allclose(v, [1, 2.3, 3, 4, 509, 6, 7, 8, 9])
+    d = np.array([1, 2.3, 4.567, 0, 0, 0], np.float32)
+    q = str(tmp_path / "b.csv")
+    ours.write_csv_contents(q.encode(), d.ctypes.data_as(C.POINTER(C.c_float)), 3, 2)      # main.c:49-50
+    assert open(q).read() == "1.000000,2.300000,4.567000,\n0.000000,0.000000,0.000000,\n"   # data/b.csv
+    f = libc.fopen; f.restype = C.c_void_p
+    fh = f(q.encode(), b"r")
+    ours.count_num_lines.argtypes = [C.c_void_p]
+    assert ours.count_num_lines(fh) == 2
+
+
+def test_csv_matches_reference(ours, theirs, tmp_path):
+    rng = np.random.default_rng(0)
+    d = (rng.normal(size=37 * 5) * 100).astype(np.float32)
+    a, b = str(tmp_path / "o.csv"), str(tmp_path / "t.csv")
+    ours.write_csv_contents(a.encode(), d.ctypes.data_as(C.POINTER(C.c_float)), 5, 37)
+    theirs.write_csv_contents(b.encode(), d.ctypes.data_as(C.POINTER(C.c_float)), 5, 37)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    va = np.ctypeslib.as_array(ours.read_csv_contents(a.encode()), shape=(185,)).copy()
+    vb = np.ctypeslib.as_array(theirs.read_csv_contents(a.encode()), shape=(185,)).copy()
+    assert np.array_equal(va, vb)
+
+
+class MnistCSV(C.Structure):
+    _fields_ = [("file", C.c_void_p), ("X", C.POINTER(C.c_float)), ("y", C.POINTER(C.c_float)), ("num_examples", C.c_int),
+                ("num_sampled", C.c_int), ("sampled", C.c_char_p)]
+
+
+class MnistExample(C.Structure):
+    _fields_ = [("X", C.POINTER(C.c_float)), ("y", C.c_float), ("num_examples", C.c_int)]
+
+
+def test_mnist_store_and_samplers_match_reference(ours, theirs, tmp_path):
+    rng = np.random.default_rng(1)
+    n = 23
+    rows = np.concatenate([rng.integers(0, 10, (n, 1)), rng.integers(0, 256, (n, 784))], 1)
+    p = str(tmp_path / "mnist.csv")
+    open(p, "w").write("".join(",".join(str(v) for v in r) + ",\n" for r in rows))
+    fopen = libc.fopen; fopen.restype = C.c_void_p
+    out = []
+    for L in (ours, theirs):
+        L.get_random_data_take.restype = MnistExample; L.get_random_data_take.argtypes = [C.POINTER(MnistCSV)]
+        L.get_random_data_replace.restype = MnistExample; L.get_random_data_replace.argtypes = [C.POINTER(MnistCSV)]
+        m = MnistCSV(fopen(p.encode(), b"r"), None, None, 0, 0, None)
+        L.mnist_csv_init(C.byref(m))
+        X = np.ctypeslib.as_array(m.X, shape=(784, n)).copy(); y = np.ctypeslib.as_array(m.y, shape=(n,)).copy()
+        libc.srand(42)                                     # model/mnist_nn.c:513
+        base = C.cast(m.X, C.c_void_p).value
+        picks = []
+        for _ in range(2 * n + 3):                         # runs past exhaustion: the sampler restarts (lib/mnist_csv2.c:43-46)
+            ex = L.get_random_data_take(C.byref(m)); picks.append(((C.cast(ex.X, C.c_void_p).value - base) // 4, ex.y))
+        for _ in range(5):
+            ex = L.get_random_data_replace(C.byref(m)); picks.append(((C.cast(ex.X, C.c_void_p).value - base) // 4, ex.y))
+        out.append((X, y, picks))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], rows[:, 1:].T.astype(np.float32))     # feature-major store
+    assert out[0][2] == out[1][2]
+    assert sorted(p[0] for p in out[0][2][:n]) == list(range(n))           # without replacement: a permutation
+
+
+class BMPData(C.Structure):
+    _fields_ = [("width", C.c_uint), ("height", C.c_uint), ("red", C.POINTER(C.c_uint8)), ("green", C.POINTER(C.c_uint8)),
+                ("blue", C.POINTER(C.c_uint8))]
+
+
+def test_bmp_and_cifar_match_reference(ours, theirs, tmp_path):
+    rng = np.random.default_rng(2)
+    batch = str(tmp_path / "data_batch_1.bin")
+    rng.integers(0, 256, 3073 * 10000, dtype=np.uint8).tofile(batch)       # a full-size batch file (30,730,000 bytes)
+    imgs = []
+    for L in (ours, theirs):
+        fd = os.open(batch, os.O_RDONLY)
+        libc.srand(7)
+        arr = np.zeros(3072, np.uint8)
+        for _ in range(3):
+            L.fill_random_data(fd, arr.ctypes.data_as(C.POINTER(C.c_uint8)))
+        os.close(fd)
+        imgs.append(arr.copy())
+    assert np.array_equal(imgs[0], imgs[1])
+    for w, h in [(32, 32), (5, 3)]:
+        planes = [rng.integers(0, 256, w * h, dtype=np.uint8) for _ in range(3)]
+        files = []
+        for i, L in enumerate((ours, theirs)):
+            d = BMPData(w, h, *[p.ctypes.data_as(C.POINTER(C.c_uint8)) for p in planes])
+            f = str(tmp_path / f"img{i}_{w}.bmp"); L.write_bmp_data(f.encode(), C.byref(d)); files.append(open(f, "rb").read())
+        assert files[0] == files[1] and files[0][:2] == b"BM" and len(files[0]) == 54 + ((24 * w + 31) // 32) * 4 * h
