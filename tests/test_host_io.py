@@ -96,7 +96,8 @@ def test_mnist_store_and_samplers_match_reference(ours, theirs, tmp_path):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][0], rows[:, 1:].T.astype(np.float32))     # feature-major store
     assert out[0][2] == out[1][2]
-    assert sorted(p[0] for p in out[0][2][:n]) == list(range(n))           # without replacement: a permutation
+    # NB the reference's "without replacement" walk stops AT the n-th unsampled slot's successor without checking that
+    # slot (lib/mnist_csv2.c:53-58), so repeats are possible; reproduced as is (the picks above are identical).
 
 
 class BMPData(C.Structure):
@@ -124,4 +125,6 @@ def test_bmp_and_cifar_match_reference(ours, theirs, tmp_path):
         for i, L in enumerate((ours, theirs)):
             d = BMPData(w, h, *[p.ctypes.data_as(C.POINTER(C.c_uint8)) for p in planes])
             f = str(tmp_path / f"img{i}_{w}.bmp"); L.write_bmp_data(f.encode(), C.byref(d)); files.append(open(f, "rb").read())
-        assert files[0] == files[1] and files[0][:2] == b"BM" and len(files[0]) == 54 + ((24 * w + 31) // 32) * 4 * h
+        # byte 47 (info header [33]) is never written by the reference (lib/bmp.c:70-72 assigns [32] twice): stack garbage there
+        assert files[0][:47] == files[1][:47] and files[0][48:] == files[1][48:]
+        assert files[0][:2] == b"BM" and len(files[0]) == 54 + ((24 * w + 31) // 32) * 4 * h
