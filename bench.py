@@ -164,15 +164,26 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
+    tstream = None
+    share_gpu = os.environ.get("BLA_BENCH_SHARE_GPU") == "1"    # rehearsal of the N > 1 code path on a one-GPU box
+    device = 0 if share_gpu else local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        backend = os.environ.get("BLA_BENCH_BACKEND", "nccl")    # "nccl" is RCCL on ROCm; "gloo" only for the rehearsal above
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+        # Every launch of ours and every collective goes through ONE explicit torch stream: RCCL orders a collective against
+        # the *current* torch stream, and our library treats a NULL stream handle as "use the library's own stream".
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
 
     from __graft_entry__ import load_pkg
     bla = load_pkg()
-    bla.init(local_rank)
+    bla.init(device)
     L = bla.lib()
     from inputs import uniform
 
@@ -182,8 +193,8 @@ def main():
     da, db, dc = bla.to_device(a), bla.to_device(b), bla.empty((n, n))
     stream = L.bla_default_stream()
     if dist is not None:
-        import torch
-        stream = torch.cuda.current_stream().cuda_stream   # RCCL orders itself against torch's current stream
+        stream = tstream.cuda_stream
+        assert stream, "need a non-NULL stream handle"
 
     def step():
         bla.gemm(da, db, dc, stream=stream)

@@ -140,7 +140,9 @@ def test_rccl_single_rank_with_torch_buckets(dev):
         grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
         torch.cuda.synchronize()
         nn.use_buckets(params_t.data_ptr(), grads_t.data_ptr())
-        stream = torch.cuda.current_stream().cuda_stream
+        ts = torch.cuda.Stream()             # explicit stream: a NULL handle would mean "the library's own stream" to bla
+        torch.cuda.set_stream(ts)
+        stream = ts.cuda_stream
         dev.mnist_nn.data_parallel_step(lambda: nn.forward_backward(stream), grads_t, lambda: nn.apply(stream=stream), dist)
         torch.cuda.synchronize()
         got = dev.mnist_nn.split_bucket(params_t.cpu().numpy())
