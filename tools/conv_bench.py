@@ -6,6 +6,9 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import time
+import oracle   # CPU restatement (checker): the reference's conv()/conv_ddx() timed beside the kernels
 from __graft_entry__ import load_pkg
 bla = load_pkg(); bla.init(0); L = bla.lib(); chk = bla.native.check
 st = L.bla_default_stream()
@@ -34,4 +37,11 @@ for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256
         t_sb = timeit(lambda: chk(L.bla_conv_backward_f32(st, dy.ptr, im.ptr, km.ptr, dq.ptr, dkm.ptr, dk.ptr, dcol.ptr, dx.ptr, h, w, k, cin, cout, 1)))
         t_ib = timeit(lambda: chk(L.bla_conv2d_backward_f32(st, dy.ptr, x.ptr, kern.ptr, dk.ptr, dx.ptr, scr.ptr, h, w, k, cin, cout, 1)))
         line += f"   bwd staged {t_sb*1e6:7.1f} us  implicit {t_ib*1e6:7.1f} us ({2*fl/t_ib/1e12:5.2f} TF/s)"
+    if cin * cout * hw <= 128 * 128 * 1024:      # CPU reference (fp64, 1 core): forward and, at stride 1, backward
+        hx = rng.uniform(-1, 1, (cin, h, w)); hk = rng.uniform(-.1, .1, (cout, cin, k, k))
+        t0 = time.perf_counter(); fw = oracle.conv_intended(hx, hk, s); tcf = time.perf_counter() - t0
+        line += f"   | CPU ref fwd {tcf*1e3:7.1f} ms"
+        if s == 1:
+            t0 = time.perf_counter(); oracle.conv_ddx_intended(rng.uniform(-1, 1, (cout, ho, ho)), fw["im2col"], fw["kmat"], cin, k); tcb = time.perf_counter() - t0
+            line += f" bwd {tcb*1e3:7.1f} ms"
     print(line, flush=True)
