@@ -55,6 +55,9 @@ SIGNATURES = {
     "bla_conv_forward_f32": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f32": (_I, [_VP] * 9 + [_I] * 6),
     "bla_conv2d_forward_f32": (_I, [_VP] * 4 + [_I] * 6), "bla_conv2d_backward_f32": (_I, [_VP] * 7 + [_I] * 6),
     "bla_group_norm_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f32": (_I, [_VP] * 6 + [_I] * 3),
+    "bla_relu_mask_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]), "bla_dropout_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]),
+    "bla_dropout_mask_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_nearest_neighbours_f32": (_I, [_VP, _VP, _VP] + [_I] * 6),
+    "bla_nearest_neighbours_ddx_f32": (_I, [_VP, _VP, _VP] + [_I] * 6), "bla_softmax_ddx_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     "bla_mnist_nn_create": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_mnist_nn_destroy": (_I, [_VP]),
     "bla_mnist_nn_param_count": (_SZ, [_VP]), "bla_mnist_nn_params": (_VP, [_VP]), "bla_mnist_nn_grads": (_VP, [_VP]),
     "bla_mnist_nn_input": (_VP, [_VP]), "bla_mnist_nn_labels": (_VP, [_VP]),

@@ -182,6 +182,19 @@ BLA_API bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_
 BLA_API bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means,
                                           const float* d_stdevs, int channels, int group_size, int hw);
 
+/* ---- U-Net glue ops around the conv path, model/cifar_unet.c; channel arrays are [C][H*W] ----
+ * _add_time_embedding (:1024-1030) is bla_add_tile_columns_f32(x, C, H*W, t, 1); _concat_skip / _split_concat
+ * (:1088-1097,1339-1349) are bla_memcpy_d2d on channel ranges; the time-bias gradient (:1191-1196) is
+ * bla_col_sum_f32(..., BLA_COLSUM_INTENDED). */
+BLA_API bla_status bla_relu_mask_f32(void* stream, float* d_dest, const float* d_source, const float* d_relu_result, size_t n);   /* multi_channel_relu_ddx, :241-253 */
+/* _dropout (:1032-1042): the reference draws `(float) rand() / RAND_MAX < DROPOUT_RATE` per element in order; the host
+ * makes those draws (same libc stream) and passes them as d_drop (non-zero = dropped). */
+BLA_API bla_status bla_dropout_f32(void* stream, const float* d_x, float* d_y, const unsigned char* d_drop, size_t n);
+BLA_API bla_status bla_dropout_mask_f32(void* stream, float* d_x, const float* d_dropout_result, size_t n);                         /* _dropout_mask, :1168-1178 */
+BLA_API bla_status bla_nearest_neighbours_f32(void* stream, const float* d_in, float* d_out, int channels, int in_h, int in_w, int out_h, int out_w, int scale);   /* :1074-1086 */
+BLA_API bla_status bla_nearest_neighbours_ddx_f32(void* stream, const float* d_source, float* d_dest, int channels, int src_h, int src_w, int dest_h, int dest_w, int scale);   /* :1229-1244 */
+BLA_API bla_status bla_softmax_ddx_f32(void* stream, const float* d_softmax_output, const float* d_gradient, float* d_out, int rows, int dim);   /* _softmax_ddx, :1246-1259 */
+
 /* ---- device-resident MNIST-NN trainer: the hot loop of model/mnist_nn.c:218-315 with everything in HBM -------
  * sizes = {n0, n1, n2, n3} (784, 256, 128, 10 in the reference, model/mnist_nn.c:25-28); samples are columns.
  * Parameters sit in one flat bucket ordered W1,b1,W2,b2,W3,b3 (each row-major), gradients in a second bucket of

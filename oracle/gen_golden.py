@@ -304,9 +304,56 @@ def gen_mnist():
     np.savez_compressed(os.path.join(GOLD, "mnist_step.npz"), **d)
 
 
+# ---- model/cifar_unet.c glue ops, called in the reference itself (oracle/_ref/libref_unet.so) ---------------
+def gen_unet_glue():
+    U = C.CDLL(os.path.join(HERE, "_ref", "libref_unet.so"))
+    libc = C.CDLL(None)
+    d = {}
+    c, h, w = 6, 8, 8
+    x = uniform(4000, (c, h, w), -1, 1); src = uniform(4001, (c, h, w), -1, 1)
+    rr = ref.inplace1("matrix_scale", x.reshape(c, h * w), C.c_double(1.0)).reshape(c, h, w).copy()
+    np.maximum(rr, 0, out=rr)                                     # a relu result (zeros where x < 0)
+    dest = np.zeros_like(x)
+    U.multi_channel_relu_ddx(ref.mats(src), ref.mats(dest), ref.mats(rr), c)
+    d["relu_mask"] = dest
+    t = uniform(4002, (c, 1)); xa = x.copy(); tm = ref.mat(t)
+    U._add_time_embedding(ref.mats(xa), C.byref(tm), c)
+    d["add_time_embedding"] = xa
+    # dropout: the draws come from libc rand(); replay them to record which elements were dropped
+    rate = C.c_float.in_dll(U, "DROPOUT_RATE").value if hasattr(U, "DROPOUT_RATE") else None
+    libc.srand(1234); y = np.zeros_like(x)
+    U._dropout(ref.mats(x), ref.mats(y), c)
+    libc.srand(1234); libc.rand.restype = C.c_int
+    RAND_MAX = 2147483647
+    draws = np.array([np.float32(libc.rand()) / np.float32(RAND_MAX) for _ in range(x.size)], np.float32)
+    d["dropout_draws"] = draws
+    d["dropout_y"] = y
+    d["dropout_dropped"] = (y == 0).astype(np.uint8).ravel()
+    g = uniform(4003, (c, h, w), -1, 1); gm = g.copy()
+    U._dropout_mask(ref.mats(gm), ref.mats(y), c)
+    d["dropout_mask"] = gm
+    for tag, (ih, iw, oh, ow, sc) in {"nn2": (4, 4, 8, 8, 2), "nn3": (3, 2, 7, 5, 3)}.items():
+        xi = uniform(4010 + sc, (c, ih, iw), -1, 1); out = np.zeros((c, oh, ow))
+        U._nearest_neighbours(ref.mats(xi), ref.mats(out), c, sc)
+        d[tag + "_up"] = out
+        gs = uniform(4020 + sc, (c, oh, ow), -1, 1); dst = np.full((c, ih, iw), 7.0)
+        U._nearest_neighbours_ddx(ref.mats(gs), ref.mats(dst), c, sc)
+        d[tag + "_ddx"] = dst
+    s_ = ref.data_fn("softmax_row_wise", uniform(4030, (16, 16), -3, 3), 16, 16); gr = uniform(4031, (16, 16), -1, 1)
+    o = np.zeros((16, 16)); ms, mg, mo = ref.mat(s_), ref.mat(gr), ref.mat(o)
+    U._softmax_ddx(C.byref(ms), C.byref(mg), C.byref(mo))
+    d["softmax_ddx_s"], d["softmax_ddx"] = s_, o
+    a = uniform(4040, (3, 4, 4)); b = uniform(4041, (3, 4, 4)); cat = np.zeros((6, 4, 4))
+    U._concat_skip(ref.mats(a), ref.mats(b), ref.mats(cat), 3)
+    d["concat"] = cat
+    half = np.zeros((3, 4, 4)); U._split_concat(ref.mats(cat), ref.mats(half), 3, 1)
+    d["split_second"] = half
+    np.savez_compressed(os.path.join(GOLD, "unet_glue.npz"), **d)
+
+
 if __name__ == "__main__":
     assert ref.available(), "build oracle/_ref first: make -C oracle"
     os.makedirs(GOLD, exist_ok=True)
-    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist()
+    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden vectors written to", GOLD, f"({tot/1e6:.2f} MB)")

@@ -327,3 +327,51 @@ def matmul_abs_f32(a, b):
     c = np.empty((a.shape[0], b.shape[1]), np.float64)
     lib().ora_matmul_abs_f32(_p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1])
     return c
+
+
+# ---- model/cifar_unet.c glue ops --------------------------------------------------------------------------
+def relu_mask(source, relu_result):
+    source = _c(source); relu_result = _c(relu_result, source.dtype)
+    dest = np.empty_like(source)
+    _call("relu_mask", source.dtype, _p(dest), _p(source), _p(relu_result), source.size)
+    return dest
+
+
+def add_channel_bias(x, t):
+    x = _c(x).copy(); t = _c(t, x.dtype)
+    _call("add_channel_bias", x.dtype, _p(x), _p(t), x.shape[0], int(np.prod(x.shape[1:])))
+    return x
+
+
+def dropout_apply(x, drop):
+    x = _c(x); drop = _c(drop, np.uint8)
+    y = np.empty_like(x)
+    _call("dropout_apply", x.dtype, _p(x), _p(y), _p(drop), x.size)
+    return y
+
+
+def dropout_mask(x, dropout_result):
+    x = _c(x).copy(); dropout_result = _c(dropout_result, x.dtype)
+    _call("dropout_mask", x.dtype, _p(x), _p(dropout_result), x.size)
+    return x
+
+
+def nearest_neighbours(x, out_h, out_w, scale):
+    x = _c(x); c, h, w = x.shape
+    out = np.empty((c, out_h, out_w), x.dtype)
+    _call("nearest_neighbours", x.dtype, _p(x), _p(out), c, w, h * w, out_h, out_w, scale)
+    return out
+
+
+def nearest_neighbours_ddx(source, dh, dw, scale):
+    source = _c(source); c, sh, sw = source.shape
+    dest = np.empty((c, dh, dw), source.dtype)
+    _call("nearest_neighbours_ddx", source.dtype, _p(source), _p(dest), c, sh, sw, dh, dw, scale)
+    return dest
+
+
+def softmax_ddx(softmax_output, gradient):
+    s = _c(softmax_output); g = _c(gradient, s.dtype)
+    out = np.empty_like(s)
+    _call("softmax_ddx", s.dtype, _p(s), _p(g), _p(out), s.shape[0], s.shape[1])
+    return out
