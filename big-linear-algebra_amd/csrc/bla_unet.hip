@@ -3,6 +3,7 @@
 // channel arrays are contiguous [C][H*W] buffers.  The adds of _nearest_neighbours_ddx are done in the reference's
 // order (row-major over the source block), so the fp32 result is bit-identical to the fp32 oracle.
 #include "bla_internal.h"
+#include <cmath>
 
 namespace bla {
 constexpr int kT = 256;
@@ -130,6 +131,59 @@ bla_status bla_softmax_ddx_f32(void* stream, const float* d_softmax_output, cons
 	hipLaunchKernelGGL(softmax_ddx_kernel, dim3((rows + 3) / 4), dim3(kT), 0, pick_stream(stream), d_softmax_output, d_gradient, d_out, rows, dim);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
+}
+
+/* ---- self-attention block, model/cifar_unet.c:999-1022 / :1261-1337, device-resident, intended composition --------
+ * x, out, del_y, del_x: [C][S] (S = H*W); wq/wk/wv: [C][d]; w: [d][C]; bias: [C].  Every matrix_transpose the reference
+ * materialises (9 of them) and both channel reshapes disappear into the GEMM's transa/transb: the [S][C] "input" matrix
+ * is X^T, so Z.Wq is a TN product on X itself, and output = dense^T comes straight out of a TT product. */
+static bla_status ep_gemm(void* s, int ta, int tb, int m, int n, int k, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha,
+                          float beta, const float* bias_row) {
+	bla_gemm_epilogue ep = {};
+	ep.alpha = alpha; ep.beta = beta; ep.bias_row = bias_row;
+	return bla_gemm_f32(s, ta, tb, m, n, k, A, lda, B, ldb, C, ldc, &ep);
+}
+
+bla_status bla_attention_forward_f32(void* stream, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv, const float* d_w,
+                                     const float* d_bias, const bla_attention_ws* ws, float* d_out, int c, int s, int d) {
+	BLA_ENTER();
+	BLA_REQUIRE(c > 0 && s > 0 && d > 0, BLA_ERR_INVALID, "bad attention shape C=%d S=%d d=%d", c, s, d);
+	BLA_REQUIRE(d_x && d_wq && d_wk && d_wv && d_w && d_bias && d_out && ws && ws->q && ws->k && ws->v && ws->scores_raw && ws->weights && ws->attention,
+	            BLA_ERR_INVALID, "null operand");
+	const float inv = (float)(1.0 / sqrt((double)d));                                                  // :1010
+	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wq, d, ws->q, d, 1.f, 0.f, nullptr); if (st) return st;   // Q = Z Wq, Z = X^T   :1003-1004
+	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wk, d, ws->k, d, 1.f, 0.f, nullptr); if (st) return st;
+	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wv, d, ws->v, d, 1.f, 0.f, nullptr); if (st) return st;
+	st = ep_gemm(stream, 0, 1, s, s, d, ws->q, d, ws->k, d, ws->scores_raw, s, inv, 0.f, nullptr); if (st) return st;   // (Q K^T) / sqrt(d)   :1007-1014
+	st = bla_memcpy_d2d(ws->weights, ws->scores_raw, (size_t)s * s * sizeof(float), stream); if (st) return st;
+	st = bla_softmax_rows_f32(stream, ws->weights, s, s); if (st) return st;                               // :1015
+	st = ep_gemm(stream, 0, 0, s, d, s, ws->weights, s, ws->v, d, ws->attention, d, 1.f, 0.f, nullptr); if (st) return st;   // :1018
+	return ep_gemm(stream, 1, 1, c, s, d, d_w, c, ws->attention, d, d_out, s, 1.f, 0.f, d_bias);              // (P W + b)^T   :1019-1021
+}
+
+bla_status bla_attention_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv,
+                                      const float* d_w, const bla_attention_ws* fw, const bla_attention_ws* g, float* d_del_wq, float* d_del_wk,
+                                      float* d_del_wv, float* d_del_w, float* d_del_x, int c, int s, int d, int jacobian_from_raw) {
+	BLA_ENTER();
+	BLA_REQUIRE(c > 0 && s > 0 && d > 0, BLA_ERR_INVALID, "bad attention shape C=%d S=%d d=%d", c, s, d);
+	BLA_REQUIRE(d_del_y && d_x && d_wq && d_wk && d_wv && d_w && fw && g && d_del_wq && d_del_wk && d_del_wv && d_del_w && d_del_x, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(g->q && g->k && g->v && g->scores_raw && g->weights && g->attention, BLA_ERR_INVALID, "null gradient workspace");
+	const float inv = (float)(1.0 / sqrt((double)d));
+	float *del_q = g->q, *del_k = g->k, *del_v = g->v, *del_i = g->scores_raw, *del_s = g->weights, *del_p = g->attention;
+	st = ep_gemm(stream, 1, 1, d, c, s, fw->attention, d, d_del_y, s, d_del_w, c, 1.f, 0.f, nullptr); if (st) return st;   // del_W = P^T del_Y'     :1291-1293
+	st = ep_gemm(stream, 1, 1, s, d, c, d_del_y, s, d_w, c, del_p, d, 1.f, 0.f, nullptr); if (st) return st;               // del_P = del_Y' W^T     :1295-1297
+	st = ep_gemm(stream, 1, 0, s, d, s, fw->weights, s, del_p, d, del_v, d, 1.f, 0.f, nullptr); if (st) return st;         // del_V = S^T del_P      :1299-1301
+	st = ep_gemm(stream, 0, 1, s, s, d, del_p, d, fw->v, d, del_s, s, 1.f, 0.f, nullptr); if (st) return st;               // del_S = del_P V^T      :1303-1305
+	st = bla_softmax_ddx_f32(stream, jacobian_from_raw ? fw->scores_raw : fw->weights, del_s, del_i, s, s); if (st) return st;   // :1307
+	st = bla_scale_f32(stream, del_i, (size_t)s * s, inv); if (st) return st;                                                // :1308
+	st = ep_gemm(stream, 0, 0, s, d, s, del_i, s, fw->k, d, del_q, d, 1.f, 0.f, nullptr); if (st) return st;               // :1310
+	st = ep_gemm(stream, 1, 0, s, d, s, del_i, s, fw->q, d, del_k, d, 1.f, 0.f, nullptr); if (st) return st;               // :1312-1314
+	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_k, d, d_del_wk, d, 1.f, 0.f, nullptr); if (st) return st;              // Z^T = X              :1316-1319
+	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_q, d, d_del_wq, d, 1.f, 0.f, nullptr); if (st) return st;
+	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_v, d, d_del_wv, d, 1.f, 0.f, nullptr); if (st) return st;
+	st = ep_gemm(stream, 0, 1, c, s, d, d_wq, d, del_q, d, d_del_x, s, 1.f, 0.f, nullptr); if (st) return st;              // del_Z^T, same add order :1322-1334
+	st = ep_gemm(stream, 0, 1, c, s, d, d_wk, d, del_k, d, d_del_x, s, 1.f, 1.f, nullptr); if (st) return st;
+	return ep_gemm(stream, 0, 1, c, s, d, d_wv, d, del_v, d, d_del_x, s, 1.f, 1.f, nullptr);
 }
 
 }  // extern "C"

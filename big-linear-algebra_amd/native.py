@@ -25,6 +25,11 @@ class Epilogue(C.Structure):
                 ("softmax_grad", C.c_void_p)]
 
 
+class AttentionWs(C.Structure):
+    """struct bla_attention_ws (include/bla.h): six device pointers."""
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "scores_raw", "weights", "attention")]
+
+
 _VP, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); every symbol include/bla.h declares must appear here (tests check both ways)
 SIGNATURES = {
@@ -58,6 +63,7 @@ SIGNATURES = {
     "bla_relu_mask_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]), "bla_dropout_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]),
     "bla_dropout_mask_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_nearest_neighbours_f32": (_I, [_VP, _VP, _VP] + [_I] * 6),
     "bla_nearest_neighbours_ddx_f32": (_I, [_VP, _VP, _VP] + [_I] * 6), "bla_softmax_ddx_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I]),
+    "bla_attention_forward_f32": (_I, [_VP] * 9 + [_I] * 3), "bla_attention_backward_f32": (_I, [_VP] * 14 + [_I] * 4),
     "bla_mnist_nn_create": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_mnist_nn_destroy": (_I, [_VP]),
     "bla_mnist_nn_param_count": (_SZ, [_VP]), "bla_mnist_nn_params": (_VP, [_VP]), "bla_mnist_nn_grads": (_VP, [_VP]),
     "bla_mnist_nn_input": (_VP, [_VP]), "bla_mnist_nn_labels": (_VP, [_VP]),

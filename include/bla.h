@@ -195,6 +195,21 @@ BLA_API bla_status bla_nearest_neighbours_f32(void* stream, const float* d_in, f
 BLA_API bla_status bla_nearest_neighbours_ddx_f32(void* stream, const float* d_source, float* d_dest, int channels, int src_h, int src_w, int dest_h, int dest_w, int scale);   /* :1229-1244 */
 BLA_API bla_status bla_softmax_ddx_f32(void* stream, const float* d_softmax_output, const float* d_gradient, float* d_out, int rows, int dim);   /* _softmax_ddx, :1246-1259 */
 
+/* Self-attention block of the U-Net (model/cifar_unet.c:999-1022 forward, :1261-1337 backward), device-resident, with the
+ * channel reshapes in the direction their call sites need (as written they are swapped and the block reads stale
+ * buffers).  x/out/del_y/del_x: [C][S], S = H*W; wq/wk/wv: [C][d]; w: [d][C]; bias: [C].
+ * Workspaces (caller allocated): q,k,v,attention [S][d]; scores_raw (= attention_weights_raw, scaled scores) and
+ * weights (= attention_weights, softmax) [S][S].  The backward's gradient workspace reuses the struct:
+ * q,k,v,attention = del_Q,del_K,del_V,del_P; scores_raw = del_I; weights = del_S.
+ * jacobian_from_raw != 0 reproduces :1307 literally (_softmax_ddx gets the RAW scores where the softmax output is meant). */
+typedef struct bla_attention_ws { float *q, *k, *v, *scores_raw, *weights, *attention; } bla_attention_ws;
+BLA_API bla_status bla_attention_forward_f32(void* stream, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv, const float* d_w,
+                                             const float* d_bias, const bla_attention_ws* ws, float* d_out, int c, int s, int d);
+BLA_API bla_status bla_attention_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_wq, const float* d_wk,
+                                              const float* d_wv, const float* d_w, const bla_attention_ws* fwd, const bla_attention_ws* grad,
+                                              float* d_del_wq, float* d_del_wk, float* d_del_wv, float* d_del_w, float* d_del_x, int c, int s, int d,
+                                              int jacobian_from_raw);
+
 /* ---- device-resident MNIST-NN trainer: the hot loop of model/mnist_nn.c:218-315 with everything in HBM -------
  * sizes = {n0, n1, n2, n3} (784, 256, 128, 10 in the reference, model/mnist_nn.c:25-28); samples are columns.
  * Parameters sit in one flat bucket ordered W1,b1,W2,b2,W3,b3 (each row-major), gradients in a second bucket of

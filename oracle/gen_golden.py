@@ -351,9 +351,68 @@ def gen_unet_glue():
     np.savez_compressed(os.path.join(GOLD, "unet_glue.npz"), **d)
 
 
+# ---- self-attention block: the reference's own call sequence (model/cifar_unet.c:999-1022,1261-1337) driven step by
+# step through its matrix.h / util.h functions and its _softmax_ddx, with the channel reshapes in the INTENDED direction
+def ref_attention(U, x, wq, wk, wv, w, bias, del_y, jac_from_raw):
+    c, hh, ww = x.shape; s = hh * ww; d = wq.shape[1]
+    T_ = lambda m: ref.inplace1("matrix_transpose", m)
+    z = np.zeros((s, c)); zm = ref.mat(z); L.reshape_matrix_channels(C.byref(zm), ref.mats(x))       # input <- X
+    q, k, v = ref.matmul_inplace(z, wq), ref.matmul_inplace(z, wk), ref.matmul_inplace(z, wv)
+    wts = ref.matmul_inplace(q, T_(k))
+    wts = ref.inplace1("matrix_scale", wts, C.c_double(1.0 / np.sqrt(float(d))))
+    raw = wts.copy()
+    wts = ref.data_fn("softmax_row_wise", wts, s, s)
+    att = ref.matmul_inplace(wts, v)
+    dense = ref.inplace2("matrix_add_tile_rows", ref.matmul_inplace(att, w), bias)
+    out = np.zeros((c, hh, ww)); dm = ref.mat(dense); L.reshape_channels_matrix(ref.mats(out), C.byref(dm))   # output <- dense
+    fwd = dict(q=q, k=k, v=v, raw=raw, wts=wts, att=att, out=out)
+    dyp = np.zeros((s, c)); dym = ref.mat(dyp); L.reshape_matrix_channels(C.byref(dym), ref.mats(del_y))
+    del_w = ref.matmul_inplace(T_(att), dyp)
+    del_p = ref.matmul_inplace(dyp, T_(w))
+    del_v = ref.matmul_inplace(T_(wts), del_p)
+    del_s = ref.matmul_inplace(del_p, T_(v))
+    jac = np.ascontiguousarray(raw if jac_from_raw else wts); del_i = np.zeros((s, s))
+    mj, ms_, mi = ref.mat(jac), ref.mat(del_s), ref.mat(del_i)
+    U._softmax_ddx(C.byref(mj), C.byref(ms_), C.byref(mi))
+    del_i = ref.inplace1("matrix_scale", del_i, C.c_double(1.0 / np.sqrt(float(d))))
+    del_q = ref.matmul_inplace(del_i, k)
+    del_k = ref.matmul_inplace(T_(del_i), q)
+    zt = T_(z)
+    del_wk, del_wq, del_wv = ref.matmul_inplace(zt, del_k), ref.matmul_inplace(zt, del_q), ref.matmul_inplace(zt, del_v)
+    del_z = ref.matmul_inplace(del_q, T_(wq))
+    del_z = ref.inplace2("matrix_add", del_z, ref.matmul_inplace(del_k, T_(wk)))
+    del_z = ref.inplace2("matrix_add", del_z, ref.matmul_inplace(del_v, T_(wv)))
+    del_x = np.zeros((c, hh, ww)); dzm = ref.mat(del_z); L.reshape_channels_matrix(ref.mats(del_x), C.byref(dzm))
+    return fwd, dict(del_wq=del_wq, del_wk=del_wk, del_wv=del_wv, del_w=del_w, del_x=del_x)
+
+
+def attention_inputs(i, c, hh, d):
+    sd = 5000 + 20 * i
+    return (uniform(sd, (c, hh, hh), -1, 1), uniform(sd + 1, (c, d), -0.2, 0.2), uniform(sd + 2, (c, d), -0.2, 0.2),
+            uniform(sd + 3, (c, d), -0.2, 0.2), uniform(sd + 4, (d, c), -0.2, 0.2), uniform(sd + 5, (1, c), -0.1, 0.1),
+            uniform(sd + 6, (c, hh, hh), -1, 1))
+
+
+def gen_attention():
+    U = C.CDLL(os.path.join(HERE, "_ref", "libref_unet.so"))
+    d = {}
+    cfgs = [(8, 3, 4), (32, 4, 16), (256, 16, 16)]   # (C, H=W, key dim); the last is the U-Net's 16x16 block (S = 256)
+    d["cfgs"] = np.array(cfgs, np.int64)
+    for i, (c, hh, kd) in enumerate(cfgs):
+        x, wq, wk, wv, w, b, dy = attention_inputs(i, c, hh, kd)
+        for tag, jr in (("intended", False), ("rawjac", True)):
+            fwd, bwd = ref_attention(U, x, wq, wk, wv, w, b, dy, jr)
+            if not jr:
+                for n, v_ in fwd.items():
+                    put(d, f"a{i}_{n}", v_, 8192)
+            for n, v_ in bwd.items():
+                put(d, f"a{i}_{tag}_{n}", v_, 8192)
+    np.savez_compressed(os.path.join(GOLD, "attention.npz"), **d)
+
+
 if __name__ == "__main__":
     assert ref.available(), "build oracle/_ref first: make -C oracle"
     os.makedirs(GOLD, exist_ok=True)
-    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue()
+    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue(); gen_attention()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden vectors written to", GOLD, f"({tot/1e6:.2f} MB)")

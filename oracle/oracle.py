@@ -375,3 +375,28 @@ def softmax_ddx(softmax_output, gradient):
     out = np.empty_like(s)
     _call("softmax_ddx", s.dtype, _p(s), _p(g), _p(out), s.shape[0], s.shape[1])
     return out
+
+
+# ---- self-attention block (model/cifar_unet.c:999-1022, 1261-1337), intended composition -------------------
+def attention_forward(x, wq, wk, wv, w, bias):
+    x = _c(x); dt = x.dtype
+    wq, wk, wv, w, bias = [_c(a, dt) for a in (wq, wk, wv, w, bias)]
+    c = x.shape[0]; s = int(np.prod(x.shape[1:])); d = wq.shape[1]
+    o = dict(q=np.empty((s, d), dt), k=np.empty((s, d), dt), v=np.empty((s, d), dt), raw=np.empty((s, s), dt),
+             wts=np.empty((s, s), dt), att=np.empty((s, d), dt), out=np.empty(x.shape, dt))
+    _call("attention_forward", dt, _p(x), _p(wq), _p(wk), _p(wv), _p(w), _p(bias), _p(o["q"]), _p(o["k"]), _p(o["v"]), _p(o["raw"]),
+          _p(o["wts"]), _p(o["att"]), _p(o["out"]), c, s, d)
+    return o
+
+
+def attention_backward(del_y, x, wq, wk, wv, w, fwd, jacobian_from_raw=False):
+    del_y = _c(del_y); dt = del_y.dtype
+    x, wq, wk, wv, w = [_c(a, dt) for a in (x, wq, wk, wv, w)]
+    c = x.shape[0]; s = int(np.prod(x.shape[1:])); d = wq.shape[1]
+    o = dict(del_wq=np.empty((c, d), dt), del_wk=np.empty((c, d), dt), del_wv=np.empty((c, d), dt), del_w=np.empty((d, c), dt),
+             del_x=np.empty(x.shape, dt))
+    f = {n: _c(fwd[n], dt) for n in ("q", "k", "v", "raw", "wts", "att")}
+    _call("attention_backward", dt, _p(del_y), _p(x), _p(wq), _p(wk), _p(wv), _p(w), _p(f["q"]), _p(f["k"]), _p(f["v"]), _p(f["raw"]),
+          _p(f["wts"]), _p(f["att"]), _p(o["del_wq"]), _p(o["del_wk"]), _p(o["del_wv"]), _p(o["del_w"]), _p(o["del_x"]), c, s, d,
+          int(jacobian_from_raw))
+    return o
