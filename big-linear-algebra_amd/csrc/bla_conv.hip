@@ -92,6 +92,7 @@ __device__ __forceinline__ double gn_block_sum(double v) {
 	return t;  // every thread gets the same total (same summation order)
 }
 
+template <bool RELU>   // RELU: multi_channel_relu fused behind the normalisation (model/cifar_unet.c:1046-1047,1056-1057)
 __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
                                                                  float* __restrict__ means, int channels, int group_size, int hw) {
 	int g = blockIdx.x;
@@ -111,7 +112,11 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __r
 		float var = (float)(gn_block_sum(q) / (double)n);
 		if (t == 0) { means[g] = mean; stdevs[g] = var; }
 #pragma unroll
-		for (int i = 0; i < kGnRegs; i++) { int j = t + i * kGnThreads; if (j < n) out[off + j] = (v[i] - mean) / var; }   // (x - mean) / (stdev + 0), lib/norm.c:44
+		for (int i = 0; i < kGnRegs; i++) {   // (x - mean) / (stdev + 0), lib/norm.c:44
+			int j = t + i * kGnThreads;
+			float y = (v[i] - mean) / var;
+			if (j < n) out[off + j] = RELU && y < 0.f ? 0.f : y;
+		}
 		return;
 	}
 	double s = 0;
@@ -121,7 +126,10 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __r
 	for (int i = t; i < n; i += kGnThreads) { float v = in[off + i] - mean; q += (double)v * v; }
 	float var = (float)(gn_block_sum(q) / (double)n);
 	if (t == 0) { means[g] = mean; stdevs[g] = var; }
-	for (int i = t; i < n; i += kGnThreads) out[off + i] = (in[off + i] - mean) / var;
+	for (int i = t; i < n; i += kGnThreads) {
+		float y = (in[off + i] - mean) / var;
+		out[off + i] = RELU && y < 0.f ? 0.f : y;
+	}
 }
 
 // lib/norm.c:52-93
@@ -530,7 +538,18 @@ bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, flo
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
+	hipLaunchKernelGGL(group_norm_kernel<false>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+bla_status bla_group_norm_relu_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
+	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
+	int groups = (channels + group_size - 1) / group_size;
+	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }

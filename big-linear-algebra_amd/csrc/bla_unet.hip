@@ -52,6 +52,11 @@ __global__ void __launch_bounds__(kT) nearest_ddx_kernel(const float* __restrict
 	}
 }
 
+// out = a + b (the residual sum at model/cifar_unet.c:1067-1071)
+__global__ void __launch_bounds__(kT) sum_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) out[i] = a[i] + b[i];
+}
+
 // _softmax_ddx, model/cifar_unet.c:1246-1259: one wave per row; out = s * (g - <s, g>)
 __global__ void __launch_bounds__(kT) softmax_ddx_kernel(const float* __restrict__ s, const float* __restrict__ g, float* __restrict__ out, int rows, int dim) {
 	int r = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -184,6 +189,71 @@ bla_status bla_attention_backward_f32(void* stream, const float* d_del_y, const 
 	st = ep_gemm(stream, 0, 1, c, s, d, d_wq, d, del_q, d, d_del_x, s, 1.f, 0.f, nullptr); if (st) return st;              // del_Z^T, same add order :1322-1334
 	st = ep_gemm(stream, 0, 1, c, s, d, d_wk, d, del_k, d, d_del_x, s, 1.f, 1.f, nullptr); if (st) return st;
 	return ep_gemm(stream, 0, 1, c, s, d, d_wv, d, del_v, d, d_del_x, s, 1.f, 1.f, nullptr);
+}
+
+bla_status bla_sum_f32(void* stream, float* d_out, const float* d_a, const float* d_b, size_t n) {
+	BLA_ENTER();
+	if (n == 0) return BLA_OK;
+	BLA_REQUIRE(d_out && d_a && d_b, BLA_ERR_INVALID, "null operand");
+	hipLaunchKernelGGL(sum_kernel, dim3(blocks_for(n)), dim3(kT), 0, pick_stream(stream), d_out, d_a, d_b, n);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+/* ---- ResNet block, model/cifar_unet.c:1044-1072 / :1180-1227, device-resident, intended composition ------------------
+ * group norm + ReLU fused; the 3x3 and 1x1 convolutions are implicit GEMMs (nothing of ConvData is materialised);
+ * the time-embedding dense layer is a 1 x T . T x Cout product with the bias in the epilogue. */
+bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                  const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size) {
+	BLA_ENTER();
+	BLA_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
+	BLA_REQUIRE(d_x && d_temb && p && d_drop && ws && d_result && p->conv1 && p->conv2 && p->time_w && p->time_b, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(cin == cout || (p->res && ws->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and workspace");
+	const int hw = h * w;
+	st = bla_group_norm_relu_f32(stream, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw); if (st) return st;         // :1046-1047
+	st = bla_conv2d_forward_f32(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1); if (st) return st;             // :1048
+	bla_gemm_epilogue ep = {};
+	ep.alpha = 1.f; ep.bias_col = p->time_b;
+	st = bla_gemm_f32(stream, 0, 0, 1, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st; // :1051-1052
+	st = bla_add_tile_columns_f32(stream, ws->c1, cout, hw, ws->tdense, 1); if (st) return st;                               // :1053
+	st = bla_group_norm_relu_f32(stream, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw); if (st) return st;      // :1056-1057
+	st = bla_dropout_f32(stream, ws->relu2, ws->dp, d_drop, (size_t)cout * hw); if (st) return st;                           // :1058
+	st = bla_conv2d_forward_f32(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1); if (st) return st;               // :1059
+	const float* r = d_x;
+	if (cin != cout) {
+		st = bla_conv2d_forward_f32(stream, d_x, p->res, ws->res, h, w, 1, cin, cout, 1); if (st) return st;                // :1062-1066
+		r = ws->res;
+	}
+	return bla_sum_f32(stream, d_result, ws->c2, r, (size_t)cout * hw);                                                      // :1067-1071
+}
+
+bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                   const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
+                                   int cin, int cout, int k, int tdim, int group_size) {
+	BLA_ENTER();
+	BLA_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
+	BLA_REQUIRE(d_del_out && d_x && d_temb && p && ws && g && sc && d_del_x && g->conv1 && g->conv2 && g->time_w && g->time_b && sc->g_out_a &&
+	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
+	const int hw = h * w;
+	// second chunk, :1186-1189
+	st = bla_conv2d_backward_f32(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, h, w, k, cout, cout, 1); if (st) return st;
+	st = bla_dropout_mask_f32(stream, sc->g_out_a, ws->dp, (size_t)cout * hw); if (st) return st;
+	st = bla_relu_mask_f32(stream, sc->g_out_a, sc->g_out_a, ws->relu2, (size_t)cout * hw); if (st) return st;
+	st = bla_group_norm_ddx_f32(stream, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw); if (st) return st;
+	// time-embedding projection, :1191-1199: bias gradient = per-channel sums, weight gradient = temb^T . dtb (rank 1)
+	st = bla_col_sum_f32(stream, sc->g_out_b, cout, hw, g->time_b, BLA_COLSUM_INTENDED); if (st) return st;
+	st = bla_gemm_f32(stream, 1, 0, tdim, cout, 1, d_temb, tdim, g->time_b, cout, g->time_w, cout, nullptr); if (st) return st;
+	// first chunk, :1202-1205 (gradient sink = the gradient struct; as written :1203 hands conv_ddx the parameters, Q8)
+	st = bla_conv2d_backward_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, sc->g_in, sc->flip, h, w, k, cin, cout, 1); if (st) return st;
+	st = bla_relu_mask_f32(stream, sc->g_in, sc->g_in, ws->relu1, (size_t)cin * hw); if (st) return st;
+	st = bla_group_norm_ddx_f32(stream, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw); if (st) return st;
+	// residual connection, :1208-1220
+	if (cin != cout) {
+		st = bla_conv2d_backward_f32(stream, d_del_out, d_x, p->res, g->res, sc->g_in, sc->flip, h, w, 1, cin, cout, 1); if (st) return st;
+		return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)cin * hw);
+	}
+	return bla_add_f32(stream, d_del_x, d_del_out, (size_t)cin * hw);
 }
 
 }  // extern "C"

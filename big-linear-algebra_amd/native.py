@@ -30,6 +30,15 @@ class AttentionWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "scores_raw", "weights", "attention")]
 
 
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(n, C.c_void_p) for n in fields], "__doc__": f"struct {name} of include/bla.h (device pointers)"})
+
+
+ResnetParams = _ptr_struct("bla_resnet_params", ("conv1", "conv2", "time_w", "time_b", "res"))
+ResnetGrads = _ptr_struct("bla_resnet_grads", ("conv1", "conv2", "time_w", "time_b", "res"))
+ResnetWs = _ptr_struct("bla_resnet_ws", ("mu1", "sd1", "relu1", "c1", "tdense", "mu2", "sd2", "relu2", "dp", "c2", "res"))
+ResnetScratch = _ptr_struct("bla_resnet_scratch", ("g_out_a", "g_out_b", "g_in", "flip"))
+
 _VP, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); every symbol include/bla.h declares must appear here (tests check both ways)
 SIGNATURES = {
@@ -64,6 +73,8 @@ SIGNATURES = {
     "bla_dropout_mask_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_nearest_neighbours_f32": (_I, [_VP, _VP, _VP] + [_I] * 6),
     "bla_nearest_neighbours_ddx_f32": (_I, [_VP, _VP, _VP] + [_I] * 6), "bla_softmax_ddx_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     "bla_attention_forward_f32": (_I, [_VP] * 9 + [_I] * 3), "bla_attention_backward_f32": (_I, [_VP] * 14 + [_I] * 4),
+    "bla_group_norm_relu_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_sum_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]),
+    "bla_resnet_forward_f32": (_I, [_VP] * 7 + [_I] * 7), "bla_resnet_backward_f32": (_I, [_VP] * 9 + [_I] * 7),
     "bla_mnist_nn_create": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_mnist_nn_destroy": (_I, [_VP]),
     "bla_mnist_nn_param_count": (_SZ, [_VP]), "bla_mnist_nn_params": (_VP, [_VP]), "bla_mnist_nn_grads": (_VP, [_VP]),
     "bla_mnist_nn_input": (_VP, [_VP]), "bla_mnist_nn_labels": (_VP, [_VP]),

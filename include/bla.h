@@ -210,6 +210,26 @@ BLA_API bla_status bla_attention_backward_f32(void* stream, const float* d_del_y
                                               float* d_del_wq, float* d_del_wk, float* d_del_wv, float* d_del_w, float* d_del_x, int c, int s, int d,
                                               int jacobian_from_raw);
 
+/* ResNet block of the U-Net (model/cifar_unet.c:1044-1072 forward, :1180-1227 backward), device-resident, intended
+ * composition (conv() delivers its result; gradients land in the gradient struct -- as written :1203,1216 hand conv_ddx
+ * the parameter kernels as the sink).  x/del_x: [Cin][H*W]; result/del_out: [Cout][H*W]; temb: [T];
+ * conv1 [Cout][Cin][k][k]; conv2 [Cout][Cout][k][k]; time_w [T][Cout]; time_b [Cout]; res [Cout][Cin][1][1] or NULL when
+ * Cin == Cout; d_drop [Cout*H*W]: the host's rand() draws, non-zero = dropped.  Stride 1. */
+typedef struct bla_resnet_params { const float *conv1, *conv2, *time_w, *time_b, *res; } bla_resnet_params;
+typedef struct bla_resnet_grads { float *conv1, *conv2, *time_w, *time_b, *res; } bla_resnet_grads;
+/* saved by the forward pass for the backward pass: mu/sd per group; relu1 [Cin][HW]; c1 (conv 1 + time embedding), relu2, dp
+ * (dropout output), c2, res (residual conv output, may be NULL when Cin == Cout) [Cout][HW]; tdense [Cout] */
+typedef struct bla_resnet_ws { float *mu1, *sd1, *relu1, *c1, *tdense, *mu2, *sd2, *relu2, *dp, *c2, *res; } bla_resnet_ws;
+/* backward scratch: g_out_a, g_out_b [Cout][HW]; g_in [Cin][HW]; flip [Cout*max(Cin,Cout)*k*k] */
+typedef struct bla_resnet_scratch { float *g_out_a, *g_out_b, *g_in, *flip; } bla_resnet_scratch;
+BLA_API bla_status bla_group_norm_relu_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw);   /* group_norm then relu, fused */
+BLA_API bla_status bla_sum_f32(void* stream, float* d_out, const float* d_a, const float* d_b, size_t n);   /* out = a + b, :1067-1071 */
+BLA_API bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                          const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size);
+BLA_API bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                           const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
+                                           int cin, int cout, int k, int tdim, int group_size);
+
 /* ---- device-resident MNIST-NN trainer: the hot loop of model/mnist_nn.c:218-315 with everything in HBM -------
  * sizes = {n0, n1, n2, n3} (784, 256, 128, 10 in the reference, model/mnist_nn.c:25-28); samples are columns.
  * Parameters sit in one flat bucket ordered W1,b1,W2,b2,W3,b3 (each row-major), gradients in a second bucket of

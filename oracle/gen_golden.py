@@ -410,9 +410,119 @@ def gen_attention():
     np.savez_compressed(os.path.join(GOLD, "attention.npz"), **d)
 
 
+# ---- ResNet block: the reference's call sequence (model/cifar_unet.c:1044-1072, 1180-1227) through its own functions,
+# in the INTENDED composition (conv output delivered, gradients into gradient structs)
+def ref_conv_fwd(x, kern, s=1):
+    cin, h, w = x.shape; cout, _, k, _ = kern.shape
+    ho = int(np.ceil(np.float32(h) / s)); wo = int(np.ceil(np.float32(w) / s))
+    im = np.zeros((ho * wo, k * k * cin)); imm = ref.mat(im)
+    L._im2col(ref.mats(x), C.byref(imm), k, cin, s)
+    km = np.zeros((k * k * cin, cout)); kmm = ref.mat(km); kp, _keep = ref.kernel_ptrs(kern)
+    L._reshape_kernels_matrix(kp, C.byref(kmm))
+    prod = ref.matmul_inplace(im, km)
+    out = np.zeros((cout, ho, wo)); pm = ref.mat(prod)
+    L.reshape_channels_matrix(ref.mats(out), C.byref(pm))
+    return out, im, km
+
+
+def ref_conv_bwd(del_y, im, km, cin, k):
+    cout, h, w = del_y.shape
+    dq = np.zeros((h * w, cout)); dqm = ref.mat(dq)
+    L.reshape_matrix_channels(C.byref(dqm), ref.mats(del_y))
+    dkm = ref.matmul_inplace(ref.inplace1("matrix_transpose", im), dq)
+    dkern = np.zeros((cout, cin, k, k)); dkp, _keep = ref.kernel_ptrs(dkern); dkmm = ref.mat(dkm)
+    L._reshape_matrix_kernels(C.byref(dkmm), dkp)
+    dcol = ref.matmul_inplace(dq, ref.inplace1("matrix_transpose", km))
+    dx = np.zeros((cin, h, w)); dcm = ref.mat(dcol)
+    L._col2im(C.byref(dcm), ref.mats(dx), k, cin, 1)
+    return dkern, dx
+
+
+def ref_group_norm(x, gs):
+    c = x.shape[0]; ng = (c + gs - 1) // gs
+    out = np.zeros_like(x); sd = np.zeros(ng); mu = np.zeros(ng)
+    L.group_norm(C.cast(ref.mats(x), ref.PM), C.cast(ref.mats(out), ref.PM), sd.ctypes.data_as(PD), mu.ctypes.data_as(PD), c, gs)
+    return out, sd, mu
+
+
+def ref_group_norm_ddx(src, data, mu, sd, gs):
+    dest = np.zeros_like(src)
+    L.group_norm_ddx(C.cast(ref.mats(src), ref.PM), C.cast(ref.mats(dest), ref.PM), C.cast(ref.mats(data), ref.PM), mu.ctypes.data_as(PD),
+                     sd.ctypes.data_as(PD), src.shape[0], gs)
+    return dest
+
+
+def resnet_inputs(i, cin, cout, hh, tdim):
+    sd = 6000 + 30 * i
+    return dict(x=uniform(sd, (cin, hh, hh), -1, 1), temb=uniform(sd + 1, (1, tdim), 0, 1), k1=uniform(sd + 2, (cout, cin, 3, 3), -0.2, 0.2),
+                k2=uniform(sd + 3, (cout, cout, 3, 3), -0.1, 0.1), tw=uniform(sd + 4, (tdim, cout), -0.1, 0.1), tb=uniform(sd + 5, (1, cout), -0.1, 0.1),
+                kres=uniform(sd + 6, (cout, cin, 1, 1), -0.3, 0.3) if cin != cout else None, del_out=uniform(sd + 7, (cout, hh, hh), -1, 1))
+
+
+def gen_resnet():
+    U = C.CDLL(os.path.join(HERE, "_ref", "libref_unet.so")); libc = C.CDLL(None)
+    L.group_norm.argtypes = [ref.PM, ref.PM, PD, PD, C.c_int, C.c_int]
+    L.group_norm_ddx.argtypes = [ref.PM, ref.PM, ref.PM, PD, PD, C.c_int, C.c_int]
+    d = {}
+    cfgs = [(3, 8, 6, 8, 32), (8, 8, 5, 16, 4), (64, 32, 8, 32, 32)]      # (Cin, Cout, H=W, time dim, group size)
+    d["cfgs"] = np.array(cfgs, np.int64)
+    for i, (cin, cout, hh, tdim, gs) in enumerate(cfgs):
+        I = resnet_inputs(i, cin, cout, hh, tdim)
+        x = I["x"]
+        relu1, sd1, mu1 = ref_group_norm(x, gs); relu1 = ref.data_fn("relu", relu1, relu1.size)
+        c1, im1, km1 = ref_conv_fwd(relu1, I["k1"])
+        tdense = ref.inplace2("matrix_add", ref.matmul_inplace(I["temb"], I["tw"]), I["tb"])
+        U._add_time_embedding(ref.mats(c1), C.byref(ref.mat(tdense)), cout)
+        relu2, sd2, mu2 = ref_group_norm(c1, gs); relu2 = ref.data_fn("relu", relu2, relu2.size)
+        libc.srand(77 + i); dp = np.zeros_like(relu2)
+        U._dropout(ref.mats(relu2), ref.mats(dp), cout)
+        libc.srand(77 + i); libc.rand.restype = C.c_int
+        draws = np.array([np.float32(libc.rand()) / np.float32(2147483647) for _ in range(relu2.size)], np.float32)
+        c2, im2, km2 = ref_conv_fwd(dp, I["k2"])
+        res = x
+        if cin != cout:
+            res, imr, kmr = ref_conv_fwd(x, I["kres"])
+        result = c2 + res                                                           # :1067-1071 (one add per element)
+        fwd = dict(mu1=mu1, sd1=sd1, relu1=relu1, c1=c1, tdense=tdense.ravel(), mu2=mu2, sd2=sd2, relu2=relu2, dp=dp, c2=c2, result=result)
+        if cin != cout:
+            fwd["res"] = res
+        d[f"r{i}_dropped"] = (draws < np.float32(0.1)).astype(np.uint8)
+        for n, v_ in fwd.items():
+            put(d, f"r{i}_{n}", v_, 8192)
+        # backward
+        dk2, g_dp = ref_conv_bwd(I["del_out"], im2, km2, cout, 3)
+        U._dropout_mask(ref.mats(g_dp), ref.mats(dp), cout)
+        g_relu2 = np.zeros_like(g_dp); U.multi_channel_relu_ddx(ref.mats(g_dp), ref.mats(g_relu2), ref.mats(relu2), cout)
+        g_c1 = ref_group_norm_ddx(g_relu2, c1, mu2, sd2, gs)
+        dtb = np.array([[sum_seq(g_c1[c].ravel()) for c in range(cout)]])
+        dtw = ref.matmul_inplace(ref.inplace1("matrix_transpose", I["temb"]), dtb)
+        dk1, g_relu1 = ref_conv_bwd(g_c1, im1, km1, cin, 3)
+        U.multi_channel_relu_ddx(ref.mats(g_relu1), ref.mats(g_relu1), ref.mats(relu1), cin)
+        del_x = ref_group_norm_ddx(g_relu1, x, mu1, sd1, gs)
+        bwd = dict(dk1=dk1, dk2=dk2, dtw=dtw, dtb=dtb.ravel())
+        if cin != cout:
+            dkres, g_res = ref_conv_bwd(I["del_out"], imr, kmr, cin, 1)
+            bwd["dkres"] = dkres
+            del_x = np.stack([ref.inplace2("matrix_add", del_x[c], g_res[c]) for c in range(cin)])
+        else:
+            del_x = np.stack([ref.inplace2("matrix_add", del_x[c], I["del_out"][c]) for c in range(cin)])
+        bwd["del_x"] = del_x
+        for n, v_ in bwd.items():
+            put(d, f"r{i}_{n}", v_, 8192)
+    np.savez_compressed(os.path.join(GOLD, "resnet.npz"), **d)
+
+
+def sum_seq(v):
+    """left-to-right fp64 sum, the order of the loop at model/cifar_unet.c:1191-1196"""
+    s_ = 0.0
+    for t in v:
+        s_ += float(t)
+    return s_
+
+
 if __name__ == "__main__":
     assert ref.available(), "build oracle/_ref first: make -C oracle"
     os.makedirs(GOLD, exist_ok=True)
-    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue(); gen_attention()
+    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue(); gen_attention(); gen_resnet()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden vectors written to", GOLD, f"({tot/1e6:.2f} MB)")

@@ -400,3 +400,35 @@ def attention_backward(del_y, x, wq, wk, wv, w, fwd, jacobian_from_raw=False):
           _p(f["wts"]), _p(f["att"]), _p(o["del_wq"]), _p(o["del_wk"]), _p(o["del_wv"]), _p(o["del_w"]), _p(o["del_x"]), c, s, d,
           int(jacobian_from_raw))
     return o
+
+
+# ---- ResNet block (model/cifar_unet.c:1044-1072, 1180-1227), intended composition ---------------------------
+def resnet_forward(x, temb, k1, k2, tw, tb, kres, drop, group_size):
+    x = _c(x); dt = x.dtype
+    temb, k1, k2, tw, tb = [_c(a, dt) for a in (temb, k1, k2, tw, tb)]
+    cin, h, w = x.shape; cout, _, k, _ = k1.shape; tdim = tw.shape[0]; hw = h * w
+    kres = _c(kres, dt) if kres is not None else None
+    drop = _c(drop, np.uint8)
+    g1 = (cin + group_size - 1) // group_size; g2 = (cout + group_size - 1) // group_size
+    o = dict(mu1=np.empty(g1, dt), sd1=np.empty(g1, dt), relu1=np.empty((cin, h, w), dt), c1=np.empty((cout, h, w), dt), tdense=np.empty(cout, dt),
+             mu2=np.empty(g2, dt), sd2=np.empty(g2, dt), relu2=np.empty((cout, h, w), dt), dp=np.empty((cout, h, w), dt), c2=np.empty((cout, h, w), dt),
+             res=np.zeros((cout, h, w), dt), result=np.empty((cout, h, w), dt))
+    _call("resnet_forward", dt, _p(x), _p(temb), _p(k1), _p(k2), _p(tw), _p(tb), _p(kres) if kres is not None else None, _p(drop),
+          *[_p(o[n]) for n in ("mu1", "sd1", "relu1", "c1", "tdense", "mu2", "sd2", "relu2", "dp", "c2", "res", "result")],
+          h, w, cin, cout, k, tdim, group_size)
+    return o
+
+
+def resnet_backward(del_out, x, temb, k1, k2, kres, fwd, group_size):
+    del_out = _c(del_out); dt = del_out.dtype
+    x, temb, k1, k2 = [_c(a, dt) for a in (x, temb, k1, k2)]
+    cin, h, w = x.shape; cout, _, k, _ = k1.shape; tdim = temb.size
+    kres = _c(kres, dt) if kres is not None else None
+    o = dict(dk1=np.empty_like(k1), dk2=np.empty_like(k2), dtw=np.empty((tdim, cout), dt), dtb=np.empty(cout, dt),
+             dkres=np.empty((cout, cin, 1, 1), dt) if kres is not None else None, del_x=np.empty_like(x))
+    f = {n: _c(fwd[n], dt) for n in ("mu1", "sd1", "relu1", "c1", "mu2", "sd2", "relu2", "dp")}
+    _call("resnet_backward", dt, _p(del_out), _p(x), _p(temb), _p(k1), _p(k2), _p(kres) if kres is not None else None,
+          *[_p(f[n]) for n in ("mu1", "sd1", "relu1", "c1", "mu2", "sd2", "relu2", "dp")],
+          _p(o["dk1"]), _p(o["dk2"]), _p(o["dtw"]), _p(o["dtb"]), _p(o["dkres"]) if kres is not None else None, _p(o["del_x"]),
+          h, w, cin, cout, k, tdim, group_size)
+    return o
