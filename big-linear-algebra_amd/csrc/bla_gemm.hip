@@ -39,6 +39,10 @@ struct GemmArgs {
 	const float* bias_row; const float* bias_col;
 	float* pre_act; int ld_pre; int act;
 	const float* relu_mask; int ld_mask;
+#ifdef BLA_WSK_DIAG
+	unsigned long long* stamps;    // diagnostics build only
+#endif
+	unsigned* counters;            // wsk kernels with splits > 1: one arrival counter per output tile (zero between launches)
 	float* row_sum_a;              // fused bias gradient: row_sum_a[r] = sum_k op(A)[r][k]   (wsk kernels, A K-contiguous)
 	const float* softmax_y; float softmax_scale; float* softmax_grad;   // fused column softmax + (p - y)*scale (wsk kernels, M <= 32)
 };
@@ -465,60 +469,100 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 // once at the end and are summed in wave order (deterministic), and the epilogue is fused -- no slab
 // kernel, no second launch.  K-contiguous operands load 16 B per lane (row l&31, k-half l>>5),
 // row-contiguous operands four coalesced dwords per lane.
-template <int NW, bool AKC, bool BKC, bool VEC>
-__global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
-	constexpr int PF = 8;  // k-groups (8 k each) per chunk = 64 k: all loads of a chunk are in flight together
-	__shared__ float red[NW][32 * 33];
+template <bool AKC, bool BKC, bool AVEC, bool BVEC>
+__global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
+	constexpr int NW = 4;  // one wave per SIMD: a CU retires 256 fp32-MFMA FLOP/clk however many waves it hosts (8 / 16 measured slower)
+	constexpr int PF = 4;  // k-groups (8 k each) per half-chunk = 32 k; two half-chunks (register sets) are in flight
+	// One LDS array: per-wave staging of row-contiguous operands during the K loop ([wave][set][operand][32 k][32]),
+	// the cross-wave reduction afterwards.
+	__shared__ __attribute__((aligned(16))) float smem[NW * 2 * 2 * 32 * 32];
+	float (*red)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
 	const int m0 = tile_m * 32, n0 = tile_n * 32;
-	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8
-	const int k_begin = wave * kw, k_end = min(p.K, k_begin + kw);
+	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8; a workgroup covers 4*kw, blockIdx.y selects which
+	const int blk_end = min(p.K, (int)(blockIdx.y + 1) * NW * kw);
+	const int k_begin = min(blk_end, ((int)blockIdx.y * NW + wave) * kw), k_end = min(blk_end, k_begin + kw);
 	const int arow = min(m0 + l31, p.M - 1), bcol = min(n0 + l31, p.N - 1);  // clamped: out-of-range rows/cols are never stored
+	float* stage = smem + wave * (2 * 2 * 32 * 32);   // [set][operand][32 k][32]
 
-	auto load = [&](int k, float (&a)[4], float (&b)[4]) {
+	// K-contiguous operand (row r of X, 4 consecutive k per lane): 16 B per lane when aligned
+	auto load_kc = [&](const float* X, int ld, int r, bool vec, int k, float (&f)[4]) {
 		const int kb = k + 4 * h;
-		if (AKC) {
-			if (VEC) {
-				float4 x = *reinterpret_cast<const float4*>(p.A + (size_t)arow * p.lda + min(kb, p.K - 4));
-				bool ok = kb < k_end;
-				a[0] = ok ? x.x : 0.f; a[1] = ok ? x.y : 0.f; a[2] = ok ? x.z : 0.f; a[3] = ok ? x.w : 0.f;
-			} else {
-#pragma unroll
-				for (int j = 0; j < 4; j++) { float x = p.A[(size_t)arow * p.lda + min(kb + j, p.K - 1)]; a[j] = kb + j < k_end ? x : 0.f; }
-			}
+		if (vec) {
+			float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ld + min(kb, p.K - 4));
+			bool ok = kb < k_end;
+			f[0] = ok ? x.x : 0.f; f[1] = ok ? x.y : 0.f; f[2] = ok ? x.z : 0.f; f[3] = ok ? x.w : 0.f;
 		} else {
 #pragma unroll
-			for (int j = 0; j < 4; j++) { float x = p.A[(size_t)min(kb + j, p.K - 1) * p.lda + arow]; a[j] = kb + j < k_end ? x : 0.f; }
-		}
-		if (BKC) {
-			if (VEC) {
-				float4 x = *reinterpret_cast<const float4*>(p.B + (size_t)bcol * p.ldb + min(kb, p.K - 4));
-				bool ok = kb < k_end;
-				b[0] = ok ? x.x : 0.f; b[1] = ok ? x.y : 0.f; b[2] = ok ? x.z : 0.f; b[3] = ok ? x.w : 0.f;
-			} else {
-#pragma unroll
-				for (int j = 0; j < 4; j++) { float x = p.B[(size_t)bcol * p.ldb + min(kb + j, p.K - 1)]; b[j] = kb + j < k_end ? x : 0.f; }
-			}
-		} else {
-#pragma unroll
-			for (int j = 0; j < 4; j++) { float x = p.B[(size_t)min(kb + j, p.K - 1) * p.ldb + bcol]; b[j] = kb + j < k_end ? x : 0.f; }
+			for (int j = 0; j < 4; j++) { float x = X[(size_t)r * ld + min(kb + j, p.K - 1)]; f[j] = kb + j < k_end ? x : 0.f; }
 		}
 	};
+	// Row-contiguous operand X[k][r], unaligned: four dword loads per lane and group
+	auto load_rc_scalar = [&](const float* X, int ld, int r, int k, float (&f)[4]) {
+		const int kb = k + 4 * h;
+#pragma unroll
+		for (int j = 0; j < 4; j++) { float x = X[(size_t)min(kb + j, p.K - 1) * ld + r]; f[j] = kb + j < k_end ? x : 0.f; }
+	};
+	// Row-contiguous operand, aligned: the wave fetches the whole 64 x 32 chunk with 8 x 16-byte loads per lane (8 lanes
+	// cover a 128-byte row segment; 32 k per half-chunk) into its private LDS slab, then every lane picks its fragment dwords from there.
+	// 4x fewer vector-memory instructions than the dword form -- the texture addresser, not the MFMA pipe, bounds these kernels.
+	auto stage_rc = [&](const float* X, int ld, int r0, int rdim, int k, float* stage) {
+		const int c4 = (lane & 7) * 4, kr = lane >> 3;
+		float4 v[PF];
+#pragma unroll
+		for (int i = 0; i < PF; i++) {
+			int kk = k + i * 8 + kr;
+			bool ok = kk < k_end && r0 + c4 < rdim;
+			float4 x = *reinterpret_cast<const float4*>(X + (size_t)min(kk, p.K - 1) * ld + min(r0 + c4, rdim - 4));
+			v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int i = 0; i < PF; i++) *reinterpret_cast<float4*>(stage + (i * 8 + kr) * 32 + c4) = v[i];
+	};
 
+#ifdef BLA_WSK_DIAG   // diagnostics build only (tools/wsk_stamps.py): s_memtime stamps of workgroup 0, wave 0
+#define BLA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (p.stamps) p.stamps[i] = t_; } } while (0)
+#else
+#define BLA_STAMP(i) do {} while (0)
+#endif
+	BLA_STAMP(0);
 	f32x16 acc;
 #pragma unroll
 	for (int r = 0; r < 16; r++) acc[r] = 0.f;
 	float rs = 0.f;   // this lane's share of sum_k A[row][k] (fused bias gradient)
 	const bool want_rs = p.row_sum_a != nullptr && tile_n == 0;
-	// Chunks of PF k-groups: ALL of a chunk's loads are issued before its first MFMA (maximum memory-level
-	// parallelism: these shapes are latency-bound), then the MFMAs consume them in order behind counted waits.
-	// The launcher sizes the wave count so that a wave's whole K extent is one chunk whenever K <= 64 * 16.
-	for (int k = k_begin; k < k_end; k += 8 * PF) {
-		float fa[PF][4], fb[PF][4];
+	// Half-chunks of PF k-groups (32 k), software-pipelined over two register sets: the loads of half-chunk t+1 are issued
+	// before the MFMAs of half-chunk t, so from the second half-chunk on the 1,000-3,000-cycle operand latency (measured
+	// with s_memtime stamps) hides under 16 MFMAs instead of adding to them.
+	auto fetch = [&](int k, int set, float (&fa)[PF][4], float (&fb)[PF][4]) {      // issue the loads of one half-chunk
+		float* st_a = stage + (set * 2 + 0) * 32 * 32;
+		float* st_b = stage + (set * 2 + 1) * 32 * 32;
+		if (!AKC && AVEC) stage_rc(p.A, p.lda, m0, p.M, k, st_a);
+		if (!BKC && BVEC) stage_rc(p.B, p.ldb, n0, p.N, k, st_b);
 #pragma unroll
-		for (int g = 0; g < PF; g++) load(k + 8 * g, fa[g], fb[g]);
+		for (int g = 0; g < PF; g++) {
+			if (AKC) load_kc(p.A, p.lda, arow, AVEC, k + 8 * g, fa[g]);
+			else if (!AVEC) load_rc_scalar(p.A, p.lda, arow, k + 8 * g, fa[g]);
+			if (BKC) load_kc(p.B, p.ldb, bcol, BVEC, k + 8 * g, fb[g]);
+			else if (!BVEC) load_rc_scalar(p.B, p.ldb, bcol, k + 8 * g, fb[g]);
+		}
+	};
+	auto consume = [&](int set, float (&fa)[PF][4], float (&fb)[PF][4]) {           // fragments from LDS (staged operands), then MFMAs
+		if ((!AKC && AVEC) || (!BKC && BVEC)) {
+			const float* st_a = stage + (set * 2 + 0) * 32 * 32;
+			const float* st_b = stage + (set * 2 + 1) * 32 * 32;
+			__builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; this only pins the compiler's order
+#pragma unroll
+			for (int g = 0; g < PF; g++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					if (!AKC && AVEC) fa[g][j] = st_a[(8 * g + 4 * h + j) * 32 + l31];
+					if (!BKC && BVEC) fb[g][j] = st_b[(8 * g + 4 * h + j) * 32 + l31];
+				}
+			__builtin_amdgcn_wave_barrier();
+		}
 		if (want_rs) {
 #pragma unroll
 			for (int g = 0; g < PF; g++) rs += (fa[g][0] + fa[g][1]) + (fa[g][2] + fa[g][3]);
@@ -527,11 +571,27 @@ __global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
 		for (int g = 0; g < PF; g++)
 #pragma unroll
 			for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
+	};
+	{
+		float fa0[PF][4], fb0[PF][4], fa1[PF][4], fb1[PF][4];
+		constexpr int KH = 8 * PF;
+		if (k_begin < k_end) fetch(k_begin, 0, fa0, fb0);
+		for (int k = k_begin; k < k_end; k += 2 * KH) {
+			if (k + KH < k_end) fetch(k + KH, 1, fa1, fb1);
+			consume(0, fa0, fb0);
+			if (k + KH < k_end) {
+				if (k + 2 * KH < k_end) fetch(k + 2 * KH, 0, fa0, fb0);
+				consume(1, fa1, fb1);
+			}
+		}
 	}
+	BLA_STAMP(20);
+	__syncthreads();   // every wave is done with its staging slabs before they are reused as the reduction buffer
+	BLA_STAMP(21);
 	// partial tiles -> LDS (stride 33: the C/D map writes 32 consecutive columns per register), sum in wave order
 #pragma unroll
 	for (int r = 0; r < 16; r++) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
-	__shared__ float red_rs[NW][64];
+	__shared__ float red_rs[4][64];
 	if (want_rs) red_rs[wave][lane] = rs;
 	__syncthreads();
 	if (want_rs && tid < 32 && m0 + tid < p.M) {
@@ -539,6 +599,45 @@ __global__ void __launch_bounds__(NW * 64) gemm_f32_wsk_kernel(GemmArgs p) {
 #pragma unroll
 		for (int w = 0; w < NW; w++) t += red_rs[w][tid] + red_rs[w][tid + 32];
 		p.row_sum_a[m0 + tid] = t;
+	}
+	if (p.splits > 1) {
+		// K is also cut over blockIdx.y (few tiles, long K: otherwise most CUs idle).  Each workgroup publishes its partial
+		// tile, draws a ticket on the tile's counter, and the LAST arriver folds the partials in split order (deterministic)
+		// and runs the epilogue -- no slab kernel, no second launch.  Hand-off per cdna_hip_programming.md "In-launch split-K
+		// reduction": plain stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 agent release fence -> vmcnt(0) ->
+		// relaxed agent fetch_add; last arriver: agent acquire fence -> vmcnt(0) -> barrier -> plain loads.  Correct for any
+		// placement of a tile's workgroups over CUs / XCDs.
+		__shared__ int is_last;
+		float* mine = p.slab + ((size_t)blockIdx.x * p.splits + blockIdx.y) * 1024;
+		for (int e = tid; e < 1024; e += NW * 64) {
+			float s = 0.f;
+#pragma unroll
+			for (int w = 0; w < NW; w++) s += red[w][(e >> 5) * 33 + (e & 31)];
+			mine[e] = s;
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tid == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			unsigned ticket = __hip_atomic_fetch_add(&p.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			is_last = ticket == (unsigned)p.splits - 1;
+			if (is_last) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(&p.counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+			}
+		}
+		__syncthreads();
+		if (!is_last) return;
+		const float* all = p.slab + (size_t)blockIdx.x * p.splits * 1024;
+		for (int e = tid; e < 1024; e += NW * 64) {
+			int r = e >> 5, c = e & 31;
+			float s = 0.f;
+			for (int z = 0; z < p.splits; z++) s += all[(size_t)z * 1024 + e];
+			if (m0 + r < p.M && n0 + c < p.N) epilogue_store(p, m0 + r, n0 + c, s);
+		}
+		return;
 	}
 	if (p.softmax_grad == nullptr) {
 		for (int e = tid; e < 1024; e += NW * 64) {
@@ -595,14 +694,16 @@ static const Config kConfigs[] = {
 	{128, 128, 16, 256, true, "glds128x128x16"},
 	{64, 64, 16, 256, true, "glds64x64x16"},
 	{128, 128, 32, 256, true, "glds128x128x32"},
-	{32, 32, 8, 256, false, "wsk32x32_w4"},     // wave-split-K, 4 / 8 / 16 waves per 32x32 tile
-	{32, 32, 8, 512, false, "wsk32x32_w8"},
-	{32, 32, 8, 1024, false, "wsk32x32_w16"},
+	{32, 32, 8, 256, false, "wsk32x32"},        // wave-split-K: 4 waves per 32x32 tile, latency-bound shapes
 	{128, 64, 16, 256, true, "glds128x64x16"},
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 static int g_force_config = -1, g_force_split = 0;
+#ifdef BLA_WSK_DIAG
+static unsigned long long* g_diag_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void bla_diag_set_stamps(void* p) { g_diag_stamps = (unsigned long long*)p; }
+#endif
 static char g_last_kernel[96] = "none";
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -655,15 +756,16 @@ static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, 
 #undef BLA_LAUNCH
 }
 
-template <int NW>
-static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool vec, dim3 grid, hipStream_t s) {
-	dim3 block(NW * 64);
-#define BLA_LAUNCH(AK, BK_, V) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<NW, AK, BK_, V>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
-	if (akc && !bkc) { if (vec) BLA_LAUNCH(true, false, true); else BLA_LAUNCH(true, false, false); }
-	if (akc && bkc) { if (vec) BLA_LAUNCH(true, true, true); else BLA_LAUNCH(true, true, false); }
-	if (!akc && !bkc) BLA_LAUNCH(false, false, false);
-	if (vec) BLA_LAUNCH(false, true, true); else BLA_LAUNCH(false, true, false);
-#undef BLA_LAUNCH
+static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, bool bvec, dim3 grid, hipStream_t s) {
+	dim3 block(256);
+#define BLA_W(AK, BK_, AV, BV) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<AK, BK_, AV, BV>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
+#define BLA_WV(AK, BK_) do { if (avec && bvec) BLA_W(AK, BK_, true, true); if (avec) BLA_W(AK, BK_, true, false); if (bvec) BLA_W(AK, BK_, false, true); BLA_W(AK, BK_, false, false); } while (0)
+	if (akc && !bkc) BLA_WV(true, false);
+	if (akc && bkc) BLA_WV(true, true);
+	if (!akc && !bkc) BLA_WV(false, false);
+	BLA_WV(false, true);
+#undef BLA_WV
+#undef BLA_W
 }
 
 }  // namespace bla
@@ -727,27 +829,51 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		                                                                  // on 4096^3 for the register-staged BK=32 kernel vs the DMA one
 		else if (vec_ok && k % 16 == 0 && k > 0) {                      // direct-to-LDS fast path; tile by how many tiles the chip gets:
 			long t128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);   // 128x128 once there are >= 2 per CU, 128x64 when that still gives
-			cfg = big_tiles >= 2 * cus ? 3 : (t128x64 >= cus ? 9 : 4);  // >= 1 per CU (2048^3: 132 vs 122 TFLOP/s), else 64x64
+			cfg = big_tiles >= 2 * cus ? 3 : (t128x64 >= cus ? 7 : 4);  // >= 1 per CU (2048^3: 132 vs 122 TFLOP/s), else 64x64
 		}
 		else cfg = big ? 0 : 1;
 	}
-	if (cfg >= 6 && cfg <= 8) {   // wave-split-K kernels: one 32x32 tile per workgroup, K divided over its waves
+	if (cfg == 6) {   // wave-split-K kernel: one 32x32 tile per workgroup, K divided over its waves
 		BLA_REQUIRE(k > 0, BLA_ERR_INVALID, "gemm config %d needs k > 0", cfg);
-		const int nw = cfg == 6 ? 4 : (cfg == 7 ? 8 : 16);
+		const int nw = 4;
 		a.tiles_m = (m + 31) / 32; a.tiles_n = (n + 31) / 32;
-		a.k_per_split = ((k + nw - 1) / nw + 7) / 8 * 8;
-		a.splits = 1; a.slab = nullptr;
-		const bool vec = k % 4 == 0 && k >= 4 && (!akc || (lda % 4 == 0 && (uintptr_t)A % 16 == 0)) && (!bkc || (ldb % 4 == 0 && (uintptr_t)B % 16 == 0));
-		dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-		hipError_t e = cfg == 6 ? launch_wsk<4>(a, akc, bkc, vec, grid, s) : cfg == 7 ? launch_wsk<8>(a, akc, bkc, vec, grid, s)
-		                                                                           : launch_wsk<16>(a, akc, bkc, vec, grid, s);
+		const long wtiles = (long)a.tiles_m * a.tiles_n;
+		int ksplit = g_force_split > 0 ? g_force_split : 1;
+		// (automatic only for long contractions: at K <= 1280 the release/acquire hand-off (~2 us per doubling) costs what the
+		// shorter K loop saves -- measured 256x784x256: 11.0 / 10.8 / 11.2 us at 1 / 2 / 4 splits)
+		if (g_force_split <= 0 && wtiles < cus && k > 1280 && !a.row_sum_a && !a.softmax_grad) {   // idle CUs and a long K: cut K over workgroups too
+			long want = (cus + wtiles - 1) / wtiles, maxs = k / 128;
+			ksplit = (int)(want < maxs ? want : maxs);
+			if (ksplit > 8) ksplit = 8;
+			if (ksplit < 1) ksplit = 1;
+		}
+		if (a.row_sum_a || a.softmax_grad || wtiles > 16384) ksplit = 1;
+		a.k_per_split = (((k + ksplit - 1) / ksplit + nw - 1) / nw + 7) / 8 * 8;   // per-wave extent
+		ksplit = (k + nw * a.k_per_split - 1) / (nw * a.k_per_split);
+		a.splits = ksplit; a.slab = nullptr; a.counters = ctx().tile_counters;
+#ifdef BLA_WSK_DIAG
+		a.stamps = g_diag_stamps;
+#endif
+		if (ksplit > 1) {
+			void* ws;
+			st = ensure_workspace((size_t)wtiles * ksplit * 1024 * sizeof(float), &ws);
+			if (st) return st;
+			a.slab = (float*)ws;
+		}
+		// 16-byte loads per operand: along K for a K-contiguous operand, along the rows/columns for a row-contiguous one
+		const bool a_al = lda % 4 == 0 && (uintptr_t)A % 16 == 0, b_al = ldb % 4 == 0 && (uintptr_t)B % 16 == 0;
+		const bool avec = a_al && (akc ? (k % 4 == 0 && k >= 4) : (m % 4 == 0 && m >= 4));
+		const bool bvec = b_al && (bkc ? (k % 4 == 0 && k >= 4) : (n % 4 == 0 && n >= 4));
+		dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)ksplit);
+		hipError_t e = launch_wsk(a, akc, bkc, avec, bvec, grid, s);
 		if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk_kernel launch");
-		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n', vec ? "vec" : "scalar");
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s%s_ksplit%d", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n',
+		         avec ? "v" : "s", bvec ? "v" : "s", ksplit);
 		return BLA_OK;
 	}
-	BLA_REQUIRE(!a.softmax_grad || (cfg >= 6 && cfg <= 8), BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K configs (6-8)");
+	BLA_REQUIRE(!a.softmax_grad || cfg == 6, BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K config (6)");
 	float* deferred_row_sum = nullptr;   // tiled kernels do not fuse the row sum: run it as a separate pass below
-	if ((cfg < 6 || cfg > 8) && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
+	if (cfg != 6 && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
 	if (kConfigs[cfg].glds && !(vec_ok && k > 0 && k % kConfigs[cfg].bk == 0)) {
 		set_error("gemm config %d (%s) needs 16-byte aligned operands, contiguous extents %% 4 == 0 and k %% %d == 0", cfg,
 		          kConfigs[cfg].name, kConfigs[cfg].bk);
@@ -795,7 +921,7 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		case 3: e = launch_glds<128, 128, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 4: e = launch_glds<64, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 5: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;   // 7
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};

@@ -14,6 +14,7 @@ struct Context {
 	hipStream_t stream = nullptr;
 	void* workspace = nullptr;      // grow-only scratch (split-K slabs, reductions)
 	size_t workspace_bytes = 0;
+	unsigned* tile_counters = nullptr;   // 16384 arrival counters for in-launch split-K, zero between launches
 	int num_cus = 0;
 	char arch[64] = {0};
 };

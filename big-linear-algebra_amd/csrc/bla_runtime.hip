@@ -82,9 +82,12 @@ bla_status bla_init(int device) {
 	if (g_ctx.ready) {  // switching device: drop the old stream/workspace
 		(void)hipStreamDestroy(g_ctx.stream);
 		if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
+		if (g_ctx.tile_counters) (void)hipFree(g_ctx.tile_counters);
 		g_ctx = Context();
 	}
 	BLA_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+	BLA_HIP(hipMalloc((void**)&g_ctx.tile_counters, 16384 * sizeof(unsigned)));
+	BLA_HIP(hipMemset(g_ctx.tile_counters, 0, 16384 * sizeof(unsigned)));
 	g_ctx.device = device;
 	g_ctx.num_cus = prop.multiProcessorCount;
 	strncpy(g_ctx.arch, prop.gcnArchName, sizeof(g_ctx.arch) - 1);
@@ -99,6 +102,7 @@ bla_status bla_shutdown(void) {
 	(void)hipDeviceSynchronize();
 	(void)hipStreamDestroy(g_ctx.stream);
 	if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
+	if (g_ctx.tile_counters) (void)hipFree(g_ctx.tile_counters);
 	g_ctx = Context();
 	return BLA_OK;
 }
