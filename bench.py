@@ -104,17 +104,43 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
     lab = randint(8, (gB,), 10); y = np.zeros((10, gB), np.float32); y[lab, np.arange(gB)] = 1
     lo, hi = mn.shard_columns(gB, world, rank)
     nn.load_batch(np.ascontiguousarray(x_raw[:, lo:hi]), np.ascontiguousarray(y[:, lo:hi]))
-    grads_t = None
+    exchange_name = "none"
+    ex = None
     if dist is not None:
         import torch
-        params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
-        grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
-        torch.cuda.synchronize()
-        nn.use_buckets(params_t.data_ptr(), grads_t.data_ptr())
+        mode = os.environ.get("BLA_BENCH_EXCHANGE", "direct")   # direct = csrc/bla_dp.hip (peer reads over xGMI), rccl = library all-reduce
+        if mode == "direct":
+            def gather(b):
+                out = [None] * world
+                dist.all_gather_object(out, b)
+                return out
+            try:
+                ex = mn.Exchange(rank, world, nn.count, gather)
+            except Exception as e:   # IPC mapping refused on this node: every rank must agree before falling back
+                print(f"[bench] rank {rank}: direct exchange unavailable ({e})", file=sys.stderr, flush=True)
+                ex = None
+            ok = torch.tensor([1 if ex is not None else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if ex is not None:
+                    ex.close()
+                ex = None
+        if ex is not None:
+            exchange_name = ("one-kernel SUM all-reduce + SGD update: every rank reads its peers' 235146-float gradient buckets "
+                             "directly over xGMI (IPC-mapped fine-grained memory, flag-synchronised), whole step = one hipGraph launch")
 
-        def step():
-            mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
-                                  lambda: nn.apply(stream=stream), dist)
+            def step():
+                nn.dp_step(ex, stream=stream)
+        else:
+            exchange_name = "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"
+            params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
+            grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
+            torch.cuda.synchronize()
+            nn.use_buckets(params_t.data_ptr(), grads_t.data_ptr())
+
+            def step():
+                mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
+                                      lambda: nn.apply(stream=stream), dist)
     else:
         def step():
             nn.graph_step(stream=stream, with_update=True)
@@ -131,9 +157,16 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
         t = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    p = bla.mnist_nn.flatten_params(nn.get_params()) if dist is None else None
-    if p is not None:
-        assert np.isfinite(p).all()
+    p = bla.mnist_nn.flatten_params(nn.get_params())
+    assert np.isfinite(p).all()
+    if ex is not None:
+        assert ex.status() == 0, "a gradient exchange timed out waiting for a peer"
+        import torch
+        # every rank must hold bit-identical parameters (the sums are taken in rank order everywhere)
+        digest = torch.tensor([float(np.frombuffer(p.tobytes(), np.uint32).astype(np.uint64).sum() % (1 << 40))], device="cuda", dtype=torch.float64)
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo.item()) == float(hi.item()), "ranks hold different parameters after the data-parallel steps"
     if rank != 0:
         return None
     flop_per_sample = 1007104   # GEMMs only, fwd 469,504 + bwd 537,600
@@ -142,7 +175,7 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
             "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4), "scaling": "weak",
             "config": {"workload": "model/mnist_nn.c 784-256-128-10 SGD step, device-resident trainer", "per_gpu_batch": per_gpu_batch,
                        "global_batch": gB, "parallelism": f"dp{world}",
-                       "exchange": "none" if world == 1 else "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"},
+                       "exchange": exchange_name},
             "gemm_flop_rate_tflops": round(sps * flop_per_sample / 1e12, 3)}
 
 

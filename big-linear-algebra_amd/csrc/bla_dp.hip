@@ -1,0 +1,229 @@
+// bla_dp.hip -- the one exchange step of the data-parallel MNIST-NN path: SUM all-reduce of the flat
+// gradient bucket, fused with the SGD update, as ONE kernel that reads the peers' buckets directly over xGMI.
+//
+// Why not a library ring: the bucket is 0.94 MB and a step is ~50 us of kernels, so the exchange is latency-bound.
+// A ring all-reduce pays 2(R-1) = 14 dependent xGMI hops; here every GPU pulls the R-1 peer buckets concurrently
+// over its R-1 point-to-point links (one hop, ~0.94 MB per link) and adds them in rank order, so
+//   * the sum is bit-identical on every rank (same order everywhere) -- parameters never drift apart,
+//   * the update `params += lr * sum` rides in the same pass (no second kernel, no extra read of the bucket),
+//   * the kernel is an ordinary graph node: a whole step (forward, backward, exchange, update) is one hipGraphLaunch.
+//
+// Synchronisation is one monotonic flag per (reader, writer) pair, pushed by the writer into the reader's memory,
+// and two gradient buckets used alternately:
+//   writer r, epoch e : [kernels fill bucket[e&1]]  ->  exchange kernel: flag[p][r] = e for every p  (system-scope release)
+//   reader p, epoch e : spin until flag[p][r] >= e for every r (system-scope acquire), then read bucket_r[e&1]
+// Rank r overwrites bucket[(e+1)&1] only after its own epoch-e exchange finished, which needed every peer's
+// epoch-e flag, which each peer pushed after completing its epoch-(e-1) exchange -- the last reader of that bucket.
+// So no second barrier is needed.  Shared memory is fine-grained (uncached in L2, coherent at system scope) and
+// exported / opened with hipIpc*MemHandle, one process per GPU.  A wait that exceeds the time-out raises the
+// status word instead of spinning forever.
+#include "bla_internal.h"
+#include <cstring>
+
+using namespace bla;
+
+namespace {
+constexpr int kMaxWorld = 16;
+constexpr long long kTimeoutTicks = 400000000LL;   // wall_clock64 runs at 100 MHz: 4 s
+
+struct DpKernelArgs {
+	const float* src[kMaxWorld];          // bucket of rank r for this parity (own: local pointer)
+	unsigned* peer_flags[kMaxWorld];      // flag array living in rank p's memory
+	unsigned* flags;                      // own flag array: flags[r] = last epoch rank r published to me
+	unsigned* state;                      // local: [0] epoch of the last finished exchange, [1] arrival counter, [2] status
+	float* out;                           // optional: out[i] = sum
+	float* target;                        // optional: target[i] += alpha * sum
+	float alpha;
+	unsigned n4;                          // float4 groups, the last one possibly partial
+	unsigned count;                       // floats in out / target (the source buckets are padded allocations)
+	int world, rank;
+};
+
+__global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
+	__shared__ int s_fail;
+	const unsigned epoch = a.state[0] + 1;   // bumped by the last workgroup of this launch, after every workgroup has read it
+	if (threadIdx.x == 0) s_fail = 0;
+	__syncthreads();
+	if (blockIdx.x == 0 && threadIdx.x < a.world) {
+		__threadfence_system();   // this rank's gradient kernels finished before this launch; make their bytes visible to the peers
+		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (threadIdx.x < a.world) {
+		const long long t0 = wall_clock64();
+		while ((int)(__hip_atomic_load(a.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+			__builtin_amdgcn_s_sleep(4);
+			if (wall_clock64() - t0 > kTimeoutTicks) { s_fail = 1; break; }
+		}
+	}
+	__syncthreads();
+	const bool fail = s_fail != 0;
+	if (!fail) {
+		for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.n4; i += gridDim.x * 256) {
+			// Plain 16-byte loads, all in flight together (one xGMI round trip per element group, not one per peer): the
+			// system-scope acquire on the flags above (buffer_inv sc0 sc1, then the workgroup barrier) already discarded every
+			// line this CU or this L2 could hold of the peers' fine-grained buckets.
+			float4 v[kMaxWorld];
+#pragma unroll
+			for (int r = 0; r < kMaxWorld; r++)
+				if (r < a.world) {
+					typedef float vf4 __attribute__((ext_vector_type(4)));
+					vf4 x = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(a.src[r]) + i);
+					v[r] = make_float4(x.x, x.y, x.z, x.w);
+				}
+			float4 s = v[0];
+#pragma unroll
+			for (int r = 1; r < kMaxWorld; r++)
+				if (r < a.world) { s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w; }   // rank order: identical on every rank
+			if (4 * i + 4 <= a.count) {
+				if (a.out) reinterpret_cast<float4*>(a.out)[i] = s;
+				if (a.target) {
+					float4 t = reinterpret_cast<float4*>(a.target)[i];
+					t.x += a.alpha * s.x; t.y += a.alpha * s.y; t.z += a.alpha * s.z; t.w += a.alpha * s.w;
+					reinterpret_cast<float4*>(a.target)[i] = t;
+				}
+			} else {   // ragged tail of a foreign (unpadded) destination
+				const float sv[4] = {s.x, s.y, s.z, s.w};
+				for (unsigned j = 0; 4 * i + j < a.count; j++) {
+					if (a.out) a.out[4 * i + j] = sv[j];
+					if (a.target) a.target[4 * i + j] += a.alpha * sv[j];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (fail) atomicOr(a.state + 2, 1u);
+		__threadfence();
+		if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {   // last workgroup: every workgroup has read state[0] and finished its reads
+			a.state[1] = 0;
+			__hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+}  // namespace
+
+struct bla_dp {
+	int rank, world;
+	size_t count, padded;        // floats; padded to a multiple of 1024
+	char* base; size_t bytes;    // own fine-grained allocation: [bucket 0][bucket 1][flags]
+	size_t flags_off;
+	unsigned* state;             // local (ordinary device memory)
+	void* peer[kMaxWorld];       // opened peer allocations (own slot = base)
+	bool connected;
+};
+
+extern "C" {
+
+bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(out && count > 0 && count < ((size_t)1 << 31), BLA_ERR_INVALID, "null / empty / oversized argument");
+	BLA_REQUIRE(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, BLA_ERR_INVALID, "rank %d / world %d (max %d)", rank, world, kMaxWorld);
+	bla_dp* dp = new bla_dp();
+	dp->rank = rank; dp->world = world; dp->count = count;
+	dp->padded = (count + 1023) / 1024 * 1024;
+	dp->flags_off = 2 * dp->padded * sizeof(float);
+	dp->bytes = dp->flags_off + 4096;
+	void* p = nullptr;
+	hipError_t e = hipExtMallocWithFlags(&p, dp->bytes, hipDeviceMallocFinegrained);
+	if (e != hipSuccess) { delete dp; return hip_fail(e, "hipExtMallocWithFlags(fine-grained exchange buffer)"); }
+	dp->base = (char*)p;
+	e = hipMemset(p, 0, dp->bytes);
+	void* s = nullptr;
+	if (e == hipSuccess) e = hipMalloc(&s, 64);
+	if (e == hipSuccess) e = hipMemset(s, 0, 64);
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	if (e != hipSuccess) { (void)hipFree(p); if (s) (void)hipFree(s); delete dp; return hip_fail(e, "exchange state allocation"); }
+	dp->state = (unsigned*)s;
+	for (int r = 0; r < kMaxWorld; r++) dp->peer[r] = nullptr;
+	dp->peer[rank] = dp->base;
+	dp->connected = world == 1;
+	*out = dp;
+	return BLA_OK;
+}
+
+bla_status bla_dp_destroy(bla_dp* dp) {
+	if (!dp) return BLA_OK;
+	(void)hipDeviceSynchronize();
+	for (int r = 0; r < dp->world; r++)
+		if (r != dp->rank && dp->peer[r]) (void)hipIpcCloseMemHandle(dp->peer[r]);
+	(void)hipFree(dp->base);
+	(void)hipFree(dp->state);
+	delete dp;
+	return BLA_OK;
+}
+
+/* 64 opaque bytes that another process passes to bla_dp_connect (hipIpcMemHandle_t of the exchange buffer). */
+bla_status bla_dp_export(bla_dp* dp, void* handle64) {
+	BLA_REQUIRE(dp && handle64, BLA_ERR_INVALID, "null argument");
+	static_assert(sizeof(hipIpcMemHandle_t) == BLA_DP_HANDLE_BYTES, "handle size");
+	hipIpcMemHandle_t h;
+	BLA_HIP(hipIpcGetMemHandle(&h, dp->base));
+	memcpy(handle64, &h, sizeof h);
+	return BLA_OK;
+}
+
+/* handles: world x 64 bytes, slot r = what rank r exported (the own slot is ignored).  Every rank must have created its
+ * exchange object before any rank connects (the caller's handle exchange is that barrier). */
+bla_status bla_dp_connect(bla_dp* dp, const void* handles) {
+	BLA_REQUIRE(dp && handles, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(!dp->connected || dp->world == 1, BLA_ERR_INVALID, "already connected");
+	for (int r = 0; r < dp->world; r++) {
+		if (r == dp->rank) continue;
+		hipIpcMemHandle_t h;
+		memcpy(&h, (const char*)handles + (size_t)r * BLA_DP_HANDLE_BYTES, sizeof h);
+		void* p = nullptr;
+		hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+		if (e != hipSuccess) {
+			set_error("hipIpcOpenMemHandle(rank %d's exchange buffer): %s", r, hipGetErrorString(e));
+			return BLA_ERR_HIP;
+		}
+		dp->peer[r] = p;
+	}
+	dp->connected = true;
+	return BLA_OK;
+}
+
+float* bla_dp_bucket(bla_dp* dp, int parity) { return dp ? (float*)(dp->base + (size_t)(parity & 1) * dp->padded * sizeof(float)) : nullptr; }
+size_t bla_dp_count(const bla_dp* dp) { return dp ? dp->count : 0; }
+
+/* sum_i = SUM over ranks r (ascending) of bucket_r[parity][i];  d_out[i] = sum_i (if d_out);  d_target[i] += alpha * sum_i
+ * (if d_target).  Collective: every rank enqueues the same sequence of calls with the same parity; parities alternate.
+ * Asynchronous on `stream`, capturable into a hipGraph (the epoch lives in device memory). */
+bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(dp, BLA_ERR_INVALID, "null exchange");
+	BLA_REQUIRE(dp->connected, BLA_ERR_INVALID, "bla_dp_connect has not run");
+	BLA_REQUIRE(((uintptr_t)d_out | (uintptr_t)d_target) % 16 == 0, BLA_ERR_INVALID, "out / target must be 16-byte aligned");
+	DpKernelArgs a = {};
+	for (int r = 0; r < dp->world; r++) {
+		a.src[r] = (const float*)((char*)dp->peer[r] + (size_t)(parity & 1) * dp->padded * sizeof(float));
+		a.peer_flags[r] = (unsigned*)((char*)dp->peer[r] + dp->flags_off);
+	}
+	a.flags = (unsigned*)(dp->base + dp->flags_off);
+	a.state = dp->state;
+	a.out = d_out; a.target = d_target; a.alpha = alpha;
+	a.n4 = (unsigned)((dp->count + 3) / 4); a.count = (unsigned)dp->count;
+	a.world = dp->world; a.rank = dp->rank;
+	unsigned blocks = (a.n4 + 255) / 256;
+	const unsigned cap = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(dp_allreduce_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+/* 0 = healthy; 1 = a wait for a peer's flag timed out in some earlier exchange (the sums of that exchange were skipped).
+ * Synchronises the device. */
+bla_status bla_dp_status(bla_dp* dp, int* status) {
+	BLA_REQUIRE(dp && status, BLA_ERR_INVALID, "null argument");
+	unsigned s[3];
+	BLA_HIP(hipDeviceSynchronize());
+	BLA_HIP(hipMemcpy(s, dp->state, sizeof s, hipMemcpyDeviceToHost));
+	*status = (int)s[2];
+	return BLA_OK;
+}
+
+}  // extern "C"

@@ -263,14 +263,14 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	constexpr int NW = WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
 	typedef KcImage<BM, BK> AI;
 	typedef KcImage<BN, BK> BI;
-	extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][A_SZ + B_SZ], all LDS in this one array
+	extern __shared__ __attribute__((aligned(16))) float lds[];  // [NBUF][A_SZ + B_SZ], all LDS in this one array
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -422,6 +422,62 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		__builtin_amdgcn_sched_barrier(0);
 	};
 
+	if constexpr (NBUF == 3) {
+		// Big-tile variant (256x128: half the DMA / barrier / LDS-read traffic per MFMA of the 128x128 tile, one residency
+		// round at 4096^3) under the 256-register budget of two waves per SIMD: only HALF a slab of fragments is
+		// prefetched across the barrier.  Sets X/Y alternate as "k-half 0 of the current / next slab", Z is k-half 1 of the
+		// current slab, read right after the barrier (2,000+ cycles of MFMAs before its first use).  Because slab t is then
+		// still being read after barrier t, the DMA of slab t+2 must not reuse its buffer: three LDS buffers.
+		static_assert(KK == 2, "split-fragment pipeline is written for BK = 16");
+		// Under a 256-register budget hipcc selects the all-VGPR MFMA forms (accumulators in architected VGPRs, measured
+		// 10-25 % slower here) unless the function visibly uses AGPRs; an "a"-constrained operand is that signal.
+		{ float agpr_hint = 0.f; asm volatile("; keep accumulators in AGPRs %0" ::"a"(agpr_hint)); }
+		float xa[TM][4], xb[TN][4], ya[TM][4], yb[TN][4], za[TM][4], zb[TN][4];
+		auto mf = [&](float (&a)[TM][4], float (&b)[TN][4], int j) {
+#pragma unroll
+			for (int im = 0; im < TM; im++)
+#pragma unroll
+				for (int in = 0; in < TN; in++) acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][j], b[in][j], acc[im][in], 0, 0, 0);
+		};
+		auto buf_of = [&](int c) { return lds + c * (A_SZ + B_SZ); };
+		// slab kt (k-half 0 in ca/cb, LDS buffer c); slab kt+1 must exist (buffer c1); DMA of slab kt+2 goes to buffer c2
+		auto step3 = [&](int c, int c1, int c2, bool do_dma, float (&ca)[TM][4], float (&cb)[TN][4], float (&na)[TM][4], float (&nb)[TN][4]) {
+			mf(ca, cb, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			frags(buf_of(c), buf_of(c) + A_SZ, 1, za, zb);
+			frags(buf_of(c1), buf_of(c1) + A_SZ, 0, na, nb);
+			if (do_dma) dma(c2);
+			__builtin_amdgcn_sched_barrier(0);
+			mf(ca, cb, 1); mf(ca, cb, 2); mf(ca, cb, 3);
+			mf(za, zb, 0); mf(za, zb, 1); mf(za, zb, 2); mf(za, zb, 3);
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		auto last3 = [&](int c, float (&ca)[TM][4], float (&cb)[TN][4]) {
+			frags(buf_of(c), buf_of(c) + A_SZ, 1, za, zb);
+			mf(ca, cb, 0); mf(ca, cb, 1); mf(ca, cb, 2); mf(ca, cb, 3);
+			mf(za, zb, 0); mf(za, zb, 1); mf(za, zb, 2); mf(za, zb, 3);
+		};
+		if (nkt > 0) {
+			dma(0);
+			if (nkt > 1) dma(1);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			frags(buf_of(0), buf_of(0) + A_SZ, 0, xa, xb);
+			int kt = 0, c = 0;
+			auto nx = [](int v) { return v == 2 ? 0 : v + 1; };
+			// Two slabs per trip so the X/Y roles are static.  The prefetch of a slab past the end is skipped by a scalar
+			// branch (the DMA has no register results, so the branch costs no copies); the fragment reads of a missing slab
+			// fetch stale LDS that is never multiplied.
+			for (; kt + 1 < nkt; kt += 2) {
+				step3(c, nx(c), nx(nx(c)), kt + 2 < nkt, xa, xb, ya, yb); c = nx(c);
+				step3(c, nx(c), nx(nx(c)), kt + 3 < nkt, ya, yb, xa, xb); c = nx(c);
+			}
+			if (nkt & 1) last3(c, xa, xb);        // odd slab count: k-half 0 of the last slab is in X
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	} else {
 	float fa0[KK][TM][4], fb0[KK][TN][4], fa1[KK][TM][4], fb1[KK][TN][4];
 	if (nkt > 0) {
 		dma(0);
@@ -444,6 +500,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			rest(fa0, fb0);
 		}
 	}
+	}   // NBUF == 2
 
 #pragma unroll
 	for (int im = 0; im < TM; im++)
@@ -696,6 +753,8 @@ static const Config kConfigs[] = {
 	{128, 128, 32, 256, true, "glds128x128x32"},
 	{32, 32, 8, 256, false, "wsk32x32"},        // wave-split-K: 4 waves per 32x32 tile, latency-bound shapes
 	{128, 64, 16, 256, true, "glds128x64x16"},
+	{128, 256, 16, 256, true, "glds128x256x16"},
+	{256, 128, 16, 256, true, "glds256x128x16"},
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -735,13 +794,13 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode
 #undef BLA_LAUNCH
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2>
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
-	size_t lds_bytes = 2 * (BM + BN) * BK * sizeof(float);
+	size_t lds_bytes = NBUF * (BM + BN) * BK * sizeof(float);
 	dim3 block(WM * WN * 64);
 #define BLA_LAUNCH(AK, BK_)                                                                                 \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW>;                                \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF>;                          \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -825,8 +884,10 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		// A CU retires 256 fp32 MFMA FLOP/clk whatever the wave count (measured: 8 or 16 waves per tile only add
 		// overhead), so a tile costs ~8*K cycles; beyond K ~ 1024 splitting K over workgroups (tiled path) wins.
 		if (((!big && tiles32 <= 512 && k <= 1280) || a.softmax_grad) && k > 0) cfg = 6;
-		else if (big && akc && bkc && vec_ok && k % 32 == 0) cfg = 2;   // NT (both operands K-contiguous): measured 130 vs 117 TFLOP/s
-		                                                                  // on 4096^3 for the register-staged BK=32 kernel vs the DMA one
+		// NT (both operands K-contiguous) on 4096^3 / 8192^3: 256x128 three-buffer DMA kernel 138.7 / 142.1 TFLOP/s, register-staged
+		// BK=32 kernel 130, 128x128 DMA kernel 116 / 119; at 2048^3 the 128x128 DMA kernel leads (126 vs 104), so only products with
+		// at least one 256x128 tile per resident slot (2 per CU) take the big tile.
+		else if (akc && bkc && vec_ok && k % 16 == 0 && (long)((m + 255) / 256) * ((n + 127) / 128) >= 2 * cus) cfg = 9;
 		else if (vec_ok && k % 16 == 0 && k > 0) {                      // direct-to-LDS fast path; tile by how many tiles the chip gets:
 			long t128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);   // 128x128 once there are >= 2 per CU, 128x64 when that still gives
 			cfg = big_tiles >= 2 * cus ? 3 : (t128x64 >= cus ? 7 : 4);  // >= 1 per CU (2048^3: 132 vs 122 TFLOP/s), else 64x64
@@ -921,7 +982,9 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		case 3: e = launch_glds<128, 128, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 4: e = launch_glds<64, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 5: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;   // 7
+		case 7: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
+		case 8: e = launch_glds<128, 256, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<256, 128, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;   // 9
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};

@@ -34,6 +34,8 @@ struct bla_mnist_nn {
 	float *z1, *a1, *z2, *a2, *z3, *a3, *dz3, *dz2, *dz1;
 	std::vector<void*> owned;
 	hipGraph_t graph; hipGraphExec_t graph_exec; bool graph_ready; int graph_colsum; float graph_lr;
+	// data-parallel step: one graph per gradient-bucket parity (the exchange object double-buffers the bucket)
+	hipGraph_t dp_graph[2]; hipGraphExec_t dp_exec[2]; bool dp_ready[2]; bla_dp* dp_bound; float dp_lr; unsigned long long dp_steps;
 };
 
 using namespace bla;
@@ -66,6 +68,7 @@ bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) 
 	nn->count = o;
 	nn->own_buckets = true;
 	nn->graph_ready = false;
+	nn->dp_ready[0] = nn->dp_ready[1] = false; nn->dp_bound = nullptr; nn->dp_lr = 0.f; nn->dp_steps = 0;
 	const size_t B = batch;
 	st = dev_alloc(nn, &nn->params, o); if (st) return st;
 	st = dev_alloc(nn, &nn->grads, o); if (st) return st;
@@ -92,6 +95,8 @@ bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) 
 bla_status bla_mnist_nn_destroy(bla_mnist_nn* nn) {
 	if (!nn) return BLA_OK;
 	if (nn->graph_ready) { (void)hipGraphExecDestroy(nn->graph_exec); (void)hipGraphDestroy(nn->graph); }
+	for (int i = 0; i < 2; i++)
+		if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); }
 	for (void* p : nn->owned) (void)hipFree(p);
 	delete nn;
 	return BLA_OK;
@@ -136,10 +141,16 @@ bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which, float** d_ptr, i
 /* Forward + backward for one batch: fills the gradient bucket (un-scaled sums over the batch columns).
  * d_x_raw: [n0][B] pixels 0..255 (scaled by 1/255.0F here, model/mnist_nn.c:218); d_y: one-hot [n3][B].
  * NULL for either means "use the trainer's resident input / label buffer". */
+static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads);
+
 bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode) {
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	return forward_backward_into(nn, stream, d_x_raw, d_y, colsum_mode, nn->grads);
+}
+
+static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads) {
 	bla_status st = require_ready();
 	if (st) return st;
-	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
 	if (!d_x_raw) d_x_raw = nn->x_raw;
 	if (!d_y) d_y = nn->y;
 	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
@@ -149,8 +160,8 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 	}
 	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
 	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
-	float *dW1 = nn->grads + nn->off[0], *db1 = nn->grads + nn->off[1], *dW2 = nn->grads + nn->off[2], *db2 = nn->grads + nn->off[3];
-	float *dW3 = nn->grads + nn->off[4], *db3 = nn->grads + nn->off[5];
+	float *dW1 = grads + nn->off[0], *db1 = grads + nn->off[1], *dW2 = grads + nn->off[2], *db2 = grads + nn->off[3];
+	float *dW3 = grads + nn->off[4], *db3 = grads + nn->off[5];
 	hipStream_t s = pick_stream(stream);
 
 	// The input scale of :218 (x *= 1/255.0F, a float expression) is folded into the two products that read X:
@@ -227,6 +238,39 @@ bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float lr, int
 		nn->graph_ready = true; nn->graph_colsum = colsum_mode * 2 + with_update; nn->graph_lr = lr;
 	}
 	BLA_HIP(hipGraphLaunch(nn->graph_exec, s));
+	return BLA_OK;
+}
+
+/* One data-parallel step as ONE graph launch: forward + backward on this rank's batch columns into the exchange object's
+ * gradient bucket of the current parity, then the fused all-reduce + update (bla_dp_allreduce_f32 with target = params,
+ * alpha = lr).  Collective: every rank calls it the same number of times.  Needs true row sums for the bias gradients
+ * (BLA_COLSUM_INTENDED): matrix_col_sum as written is not separable over columns. */
+bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn && dp, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(colsum_mode == BLA_COLSUM_INTENDED, BLA_ERR_INVALID, "a sharded batch needs BLA_COLSUM_INTENDED (true row sums)");
+	BLA_REQUIRE(bla_dp_count(dp) == nn->count, BLA_ERR_SHAPE, "exchange bucket holds %zu floats, the trainer has %zu parameters", bla_dp_count(dp), nn->count);
+	hipStream_t s = pick_stream(stream);
+	if (nn->dp_bound != dp || nn->dp_lr != lr) {
+		for (int i = 0; i < 2; i++)
+			if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
+		nn->dp_bound = dp; nn->dp_lr = lr;
+	}
+	const int par = (int)(nn->dp_steps & 1);
+	if (!nn->dp_ready[par]) {
+		BLA_HIP(hipStreamSynchronize(s));
+		BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+		st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par));
+		if (!st) st = bla_dp_allreduce_f32(dp, s, par, nullptr, nn->params, lr);
+		hipError_t e = hipStreamEndCapture(s, &nn->dp_graph[par]);
+		if (st) { if (e == hipSuccess) (void)hipGraphDestroy(nn->dp_graph[par]); return st; }
+		if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+		BLA_HIP(hipGraphInstantiate(&nn->dp_exec[par], nn->dp_graph[par], nullptr, nullptr, 0));
+		nn->dp_ready[par] = true;
+	}
+	BLA_HIP(hipGraphLaunch(nn->dp_exec[par], s));
+	nn->dp_steps++;
 	return BLA_OK;
 }
 

@@ -111,6 +111,43 @@ class MnistNN:
     def graph_step(self, lr=LEARN_RATE, stream=None, with_update=True):
         native.check(self.L.bla_mnist_nn_graph_step(self.h, stream, lr, self.colsum_mode, int(with_update)))
 
+    def dp_step(self, exchange, lr=LEARN_RATE, stream=None):
+        """One data-parallel step (forward, backward, direct-xGMI all-reduce fused with the update) as one graph launch."""
+        native.check(self.L.bla_mnist_nn_dp_step(self.h, exchange.h, stream, lr, self.colsum_mode))
+
+
+class Exchange:
+    """bla_dp_*: the gradient exchange of the data-parallel step.  `all_gather_bytes(b) -> [bytes per rank]` is any
+    host-side channel (torch.distributed.all_gather_object, MPI, ...): it only carries the 64-byte IPC handles once."""
+
+    def __init__(self, rank, world, count, all_gather_bytes=None):
+        self.L = native.lib()
+        h = C.c_void_p()
+        native.check(self.L.bla_dp_create(C.byref(h), rank, world, count))
+        self.h, self.rank, self.world, self.count = h, rank, world, count
+        if world > 1:
+            buf = C.create_string_buffer(64)
+            native.check(self.L.bla_dp_export(self.h, buf))
+            handles = all_gather_bytes(buf.raw)
+            assert len(handles) == world and all(len(x) == 64 for x in handles)
+            native.check(self.L.bla_dp_connect(self.h, b"".join(handles)))
+
+    def bucket(self, parity):
+        return self.L.bla_dp_bucket(self.h, parity)
+
+    def allreduce(self, parity, out=None, target=None, alpha=0.0, stream=None):
+        native.check(self.L.bla_dp_allreduce_f32(self.h, stream, parity, out, target, alpha))
+
+    def status(self):
+        s = C.c_int()
+        native.check(self.L.bla_dp_status(self.h, C.byref(s)))
+        return s.value
+
+    def close(self):
+        if self.h:
+            self.L.bla_dp_destroy(self.h)
+            self.h = None
+
 
 def shard_columns(n_cols, world, rank):
     """Columns [lo, hi) of a batch that rank `rank` of `world` owns (model/mnist_nn.c has samples as columns;

@@ -256,6 +256,30 @@ BLA_API bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const
 /* Same step from the resident buffers, captured once into a hipGraph and replayed (launch-bound otherwise). */
 BLA_API bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float lr, int colsum_mode, int with_update);
 
+/* ---- data-parallel exchange (the one exchange step of the MNIST-NN path) ------------------------
+ * The reference has no multi-device code; this is what a data-parallel driver of model/mnist_nn.c needs between
+ * backward (:260-293) and the update (:296-315): SUM of the flat gradient bucket over the ranks (the reference's
+ * gradient is a sum over batch columns, so no rescale).  One process per GPU; each rank owns two gradient buckets
+ * (used alternately) in fine-grained memory that the peers map through IPC and read directly over xGMI; the sum is
+ * taken in rank order on every rank (bit-identical results) and the update is fused.  See csrc/bla_dp.hip. */
+typedef struct bla_dp bla_dp;
+#define BLA_DP_HANDLE_BYTES 64
+BLA_API bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count /* floats per bucket */);
+BLA_API bla_status bla_dp_destroy(bla_dp* dp);
+/* 64 opaque bytes for the other ranks (exchange them with any host-side channel: MPI, torch.distributed, a file) */
+BLA_API bla_status bla_dp_export(bla_dp* dp, void* handle64);
+/* handles: world x 64 bytes, slot r = rank r's export (own slot ignored); call once, after every rank has exported */
+BLA_API bla_status bla_dp_connect(bla_dp* dp, const void* handles);
+BLA_API float* bla_dp_bucket(bla_dp* dp, int parity);   /* device pointer of this rank's bucket 0 / 1 */
+BLA_API size_t bla_dp_count(const bla_dp* dp);
+/* sum_i = SUM_r bucket_r[parity][i] (r ascending); d_out[i] = sum_i if d_out; d_target[i] += alpha * sum_i if d_target.
+ * Collective and asynchronous on `stream`; successive calls alternate the parity; capturable into a hipGraph. */
+BLA_API bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha);
+/* *status = 0 healthy, 1 = some earlier exchange gave up waiting for a peer (4 s) and skipped its sums; synchronises */
+BLA_API bla_status bla_dp_status(bla_dp* dp, int* status);
+/* forward + backward + exchange + update of one data-parallel step as one graph launch (BLA_COLSUM_INTENDED only) */
+BLA_API bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
+
 #ifdef __cplusplus
 }
 #endif

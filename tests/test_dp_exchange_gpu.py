@@ -1,0 +1,100 @@
+"""Multi-process test of the data-parallel exchange (csrc/bla_dp.hip) on the GPU box: `world` processes,
+each with its own HIP context, map each other's gradient buckets through IPC and run the one-kernel all-reduce +
+update.  Checks: sums bit-exact against a rank-ordered float32 sum; parameters bit-identical on every rank; equal to
+the single-device full-batch step of the same trainer to fp32 summation-order tolerance (1e-6 normwise, SURVEY 8(d)
+cfg 4)."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from inputs import uniform, randint
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "helpers", "dp_worker.py")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from __graft_entry__ import load_pkg
+    bla = load_pkg(); bla.init(0)
+    return bla
+
+
+def run_ranks(world, tmp, steps, per):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(tmp), str(steps), str(per)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs, failed = [], False
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, _ = p.communicate(); failed = True
+        outs.append(o)
+        failed |= p.returncode != 0
+    assert not failed, "\n---\n".join(outs)
+    return [np.load(os.path.join(tmp, f"result{r}.npz")) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_between_processes(dev, world, tmp_path):
+    steps, per = 3, 64
+    res = run_ranks(world, str(tmp_path), steps, per)
+    count = 10007
+    tgt = np.full(count, 1.0, np.float32)
+    for rnd in range(3):
+        s = uniform(1000 * rnd + 0, (count,), -1, 1, np.float32).copy()
+        for r in range(1, world):
+            s = s + uniform(1000 * rnd + r, (count,), -1, 1, np.float32)      # rank order, fp32
+        for r in range(world):
+            assert np.array_equal(res[r][f"sum{rnd}"], s), f"round {rnd} rank {r}"
+        tgt = tgt + np.float32(0.5) * s
+    for r in range(world):
+        assert int(res[r]["status_a"]) == 0 and int(res[r]["status_b"]) == 0
+        np.testing.assert_allclose(res[r]["target"], tgt, rtol=1e-6, atol=1e-6)   # the update may contract into an FMA
+        assert np.array_equal(res[r]["params"], res[0]["params"]), f"rank {r} parameters differ from rank 0's"
+
+    # single device, full batch, same trainer
+    mn = dev.mnist_nn
+    gB = per * world
+    nn = mn.MnistNN(gB, colsum_mode=mn.COLSUM_INTENDED)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+    x_raw = randint(7, (784, gB), 256).astype(np.float32)
+    lab = randint(8, (gB,), 10); y = np.zeros((10, gB), np.float32); y[lab, np.arange(gB)] = 1
+    nn.load_batch(x_raw, y)
+    p0 = mn.flatten_params(nn.get_params())
+    for _ in range(steps):
+        nn.train_step()
+    single = mn.flatten_params(nn.get_params())
+    got = res[0]["params"]
+    assert np.linalg.norm(single - p0) > 0
+    err = np.linalg.norm(got - single) / np.linalg.norm(single)
+    assert err <= 1e-6, err
+    # the update itself (what the exchange carries) to 1e-4 of its own size
+    assert np.linalg.norm((got - p0) - (single - p0)) <= 1e-4 * np.linalg.norm(single - p0)
+
+
+def test_single_rank_exchange_is_the_plain_step(dev):
+    """world = 1: dp_step (graph: forward, backward into the exchange bucket, fused sum + update) == train_step."""
+    mn = dev.mnist_nn
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    x_raw = randint(7, (784, 256), 256).astype(np.float32)
+    lab = randint(8, (256,), 10); y = np.zeros((10, 256), np.float32); y[lab, np.arange(256)] = 1
+    outs = []
+    for mode in ("dp", "plain"):
+        nn = mn.MnistNN(256, colsum_mode=mn.COLSUM_INTENDED)
+        nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+        nn.load_batch(x_raw, y)
+        if mode == "dp":
+            ex = mn.Exchange(0, 1, nn.count)
+            for _ in range(4):
+                nn.dp_step(ex)
+            assert ex.status() == 0
+        else:
+            for _ in range(4):
+                nn.train_step()
+        outs.append(mn.flatten_params(nn.get_params()))
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-6, atol=1e-7)

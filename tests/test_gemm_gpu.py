@@ -59,17 +59,20 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
-    Configs 3-5 and 7 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0.
+    Configs 3-5 and 7-9 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0
+    (8 and 9 are the three-buffer split-fragment pipeline; odd and even slab counts take different tails).
     Config 6 is the wave-split-K kernel for latency-bound shapes (any shape, k > 0)."""
     dev.lib().bla_gemm_set_config(cfg, 0)
     shapes = [(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128), (257, 100, 31), (200, 260, 136)]
-    if 3 <= cfg <= 5 or cfg == 7:
+    if 3 <= cfg <= 5 or cfg >= 7:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
-                  (384, 512, 256)]
+                  (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128)]
+        if cfg == 5:
+            shapes = [s for s in shapes if s[1] % 32 == 0]
     try:
         for j, (m, k, n) in enumerate(shapes):
             a = uniform(10 + j, (k, m) if ta else (m, k), dtype=np.float32)
