@@ -199,6 +199,11 @@ struct ConvArgs {
 	int tiles_n, kw;             // kw: K extent per wave (multiple of 8)
 	int splits, k_per_split;     // K is also cut over blockIdx.y; partial products go to slab[split][M][N]
 	float* slab;
+	// batch of images sharing the kernels (the reference has no batch dimension: each image is one conv() call).
+	// FWD: image index = blockIdx.z, A shared.  WGRAD: the contraction runs over (image, pixel): blockIdx.y = image * psplits + k-split,
+	// A (= del_y) and the image advance per image, every (image, k-split) pair writes its own slab.
+	int batch, psplits;
+	size_t img_stride, out_stride, a_stride;
 	ConvGeom g;
 };
 
@@ -222,8 +227,12 @@ __global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
 	const int l31 = lane & 31, h = lane >> 5;
 	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
 	const int m0 = tile_m * 32, n0 = tile_n * 32;
-	const int split_end = min(p.K, (int)(blockIdx.y + 1) * p.k_per_split);
-	const int k_begin = min(split_end, (int)blockIdx.y * p.k_per_split + wave * p.kw), k_end = min(split_end, k_begin + p.kw);
+	const int image = MODE == CONV_FWD ? (int)blockIdx.z : (int)blockIdx.y / p.psplits;
+	const int ks = MODE == CONV_FWD ? (int)blockIdx.y : (int)blockIdx.y % p.psplits;
+	p.img += (size_t)image * p.img_stride; p.A += (size_t)image * p.a_stride;
+	if (MODE == CONV_FWD) { p.out += (size_t)image * p.out_stride; if (p.slab) p.slab += (size_t)image * p.splits * p.M * p.N; }
+	const int split_end = min(p.K, (ks + 1) * p.k_per_split);
+	const int k_begin = min(split_end, ks * p.k_per_split + wave * p.kw), k_end = min(split_end, k_begin + p.kw);
 	const int arow = min(m0 + l31, p.M - 1);
 	const int ncol = min(n0 + l31, p.N - 1);
 	const ConvGeom g = p.g;
@@ -295,13 +304,15 @@ __global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
 	}
 }
 
-// folds the K-split slabs in split order (deterministic)
+// folds the K-split slabs in split order (deterministic); blockIdx.y = image for a batched forward
 __global__ void __launch_bounds__(kThreads) conv_slab_reduce_kernel(ConvArgs p) {
 	size_t total = (size_t)p.M * p.N;
+	const float* slab = p.slab + (size_t)blockIdx.y * p.splits * total;
+	float* out = p.out + (size_t)blockIdx.y * p.out_stride;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		float s = 0.f;
-		for (int z = 0; z < p.splits; z++) s += p.slab[(size_t)z * total + i];
-		p.out[(i / p.N) * p.ldo + i % p.N] = s;
+		for (int z = 0; z < p.splits; z++) s += slab[(size_t)z * total + i];
+		out[(i / p.N) * p.ldo + i % p.N] = s;
 	}
 }
 
@@ -337,31 +348,37 @@ static bla_status get_table(hipStream_t s, const ConvGeom& g, const int2** out) 
 }
 
 template <int MODE>
-static bla_status launch_implicit(hipStream_t s, ConvArgs& a) {
+static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, size_t img_stride = 0, size_t out_stride = 0, size_t a_stride = 0) {
+	a.batch = batch; a.img_stride = img_stride; a.out_stride = out_stride; a.a_stride = a_stride;
 	a.tiles_n = (a.N + 31) / 32;
 	int tiles = ((a.M + 31) / 32) * a.tiles_n;
 	// long contractions over few tiles are latency-bound: cut K over workgroups until ~3 of them sit on every CU,
-	// keeping >= 128 k per workgroup
-	int splits = (768 + tiles - 1) / tiles;
+	// keeping >= 128 k per workgroup (a batch multiplies the workgroups of a forward pass, and the K-splits of a weight gradient)
+	int splits = (768 + tiles * batch - 1) / (tiles * batch);
 	if (splits > a.K / 128) splits = a.K / 128;
 	if (splits < 1) splits = 1;
 	if (splits > 32) splits = 32;
 	a.k_per_split = ((a.K + splits - 1) / splits + 31) / 32 * 32;
 	splits = (a.K + a.k_per_split - 1) / a.k_per_split;
-	a.splits = splits;
 	a.kw = a.k_per_split / 4;   // multiple of 8
 	a.slab = nullptr;
-	if (splits > 1) {
+	a.psplits = splits;
+	const bool wgrad = MODE == CONV_WGRAD;
+	a.splits = wgrad ? splits * batch : splits;          // slabs folded into one output
+	if (a.splits > 1) {
 		void* ws;
-		bla_status st = ensure_workspace((size_t)splits * a.M * a.N * sizeof(float), &ws);
+		size_t slabs = (size_t)splits * batch;
+		bla_status st = ensure_workspace(slabs * a.M * a.N * sizeof(float), &ws);
 		if (st) return st;
 		a.slab = (float*)ws;
 	}
-	dim3 grid((unsigned)tiles, (unsigned)splits);
-	bool vec = a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0;
+	BLA_REQUIRE((long)splits * batch <= 65535 && batch <= 65535, BLA_ERR_INVALID, "batch %d too large for one launch", batch);
+	dim3 grid((unsigned)tiles, (unsigned)(wgrad ? splits * batch : splits), (unsigned)(wgrad ? 1 : batch));
+	bool vec = a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0 && a.a_stride % 4 == 0;
 	if (vec) hipLaunchKernelGGL((conv_implicit_kernel<MODE, true>), grid, dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((conv_implicit_kernel<MODE, false>), grid, dim3(256), 0, s, a);
-	if (splits > 1) hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(grid_for((size_t)a.M * a.N)), dim3(kThreads), 0, s, a);
+	if (a.splits > 1)
+		hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(grid_for((size_t)a.M * a.N), (unsigned)(wgrad ? 1 : batch)), dim3(kThreads), 0, s, a);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -472,10 +489,10 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
 
 /* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
  * same values as conv()'s `output` (lib/conv.c:205-212, intended composition), any stride. */
-bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride) {
+static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
 	bla_status st = require_ready();
 	if (st) return st;
-	BLA_REQUIRE(h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
+	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
 	BLA_REQUIRE(d_x && d_kern && d_out, BLA_ERR_INVALID, "null operand");
 	hipStream_t s = pick_stream(stream);
 	Geometry gm = same_geometry(h, w, k, stride);
@@ -485,21 +502,18 @@ bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d
 	if (st) return st;
 	a.A = d_kern; a.lda = k * k * c_in; a.img = d_x; a.out = d_out; a.ldo = gm.ho * gm.wo;
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
-	return launch_implicit<CONV_FWD>(s, a);
+	return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
 }
 
-/* Gradients of the same convolution (conv_ddx, lib/conv.c:214-229, intended composition) without del_Q / del_col:
- *   d_del_kern [F][C][k][k] = sum over output pixels of del_y x patches     (any stride)
- *   d_del_x    [C][H][W]    = conv(del_y, kernels transposed + flipped)     (stride 1 only, as in the reference)
- * Either output may be NULL.  d_scratch holds the flipped kernels (F*C*k*k floats) when d_del_x is requested. */
-bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
-                                   float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride) {
+static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
+                                  float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
 	bla_status st = require_ready();
 	if (st) return st;
-	BLA_REQUIRE(h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
+	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
 	BLA_REQUIRE(d_del_y, BLA_ERR_INVALID, "null operand");
 	hipStream_t s = pick_stream(stream);
 	Geometry gm = same_geometry(h, w, k, stride);
+	const size_t x_sz = (size_t)c_in * h * w, y_sz = (size_t)f_n * gm.ho * gm.wo;
 	if (d_del_kern) {
 		BLA_REQUIRE(d_x, BLA_ERR_INVALID, "weight gradient needs the forward input");
 		ConvArgs a;
@@ -508,7 +522,7 @@ bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const flo
 		if (st) return st;
 		a.A = d_del_y; a.lda = gm.ho * gm.wo; a.img = d_x; a.out = d_del_kern; a.ldo = k * k * c_in;
 		a.M = f_n; a.N = k * k * c_in; a.K = gm.ho * gm.wo;
-		st = launch_implicit<CONV_WGRAD>(s, a);
+		st = launch_implicit<CONV_WGRAD>(s, a, batch, x_sz, 0, y_sz);
 		if (st) return st;
 	}
 	if (d_del_x) {
@@ -526,10 +540,39 @@ bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const flo
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = d_del_y; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
-		st = launch_implicit<CONV_FWD>(s, a);
+		st = launch_implicit<CONV_FWD>(s, a, batch, y_sz, x_sz, 0);
 		if (st) return st;
 	}
 	return BLA_OK;
+}
+
+/* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
+ * same values as conv()'s `output` (lib/conv.c:205-212, intended composition), any stride. */
+bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, 1, h, w, k, c_in, f_n, stride);
+}
+
+/* Gradients of the same convolution (conv_ddx, lib/conv.c:214-229, intended composition) without del_Q / del_col:
+ *   d_del_kern [F][C][k][k] = sum over output pixels of del_y x patches     (any stride)
+ *   d_del_x    [C][H][W]    = conv(del_y, kernels transposed + flipped)     (stride 1 only, as in the reference)
+ * Either output may be NULL.  d_scratch holds the flipped kernels (F*C*k*k floats) when d_del_x is requested. */
+bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
+                                   float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride) {
+	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, 1, h, w, k, c_in, f_n, stride);
+}
+
+/* `batch` images through the same kernels in one launch (SURVEY 8(d) cfg 5 "batch of 64"): x [B][C][H][W] -> out [B][F][Ho][Wo],
+ * every image exactly what bla_conv2d_forward_f32 gives for it.  The reference has no batch dimension (one conv() per image). */
+bla_status bla_conv2d_forward_batched_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in,
+                                          int f_n, int stride) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride);
+}
+
+/* Batched gradients: d_del_x [B][C][H][W] per image; d_del_kern = SUM over the images of the per-image weight gradient
+ * (slabs per (image, k-split) folded in image order -- deterministic), i.e. what `batch` conv_ddx calls accumulate to. */
+bla_status bla_conv2d_backward_batched_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
+                                           float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
+	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride);
 }
 
 bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw) {

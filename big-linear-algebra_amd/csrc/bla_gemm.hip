@@ -263,7 +263,7 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	constexpr int NW = WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -277,58 +277,61 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	const int l31 = lane & 31, h = lane >> 5;
 	const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
-	int pid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-	constexpr int GROUP_M = 8;
-	int per_group = GROUP_M * p.tiles_n;
-	int first_m = (pid / per_group) * GROUP_M;
-	int gsz = min(p.tiles_m - first_m, GROUP_M);
-	int tile_m = first_m + (pid % per_group) % gsz, tile_n = (pid % per_group) / gsz;
-	const int m0 = tile_m * BM, n0 = tile_n * BN;
+	// virtual block id -> tile origin: XCD remap, then groups of 8 tile-rows walked column by column
+	auto tile_origin = [&](int vb, int& tm0, int& tn0) {
+		int pid = xcd_remap(vb, p.tiles_m * p.tiles_n);
+		constexpr int GROUP_M = 8;
+		int per_group = GROUP_M * p.tiles_n;
+		int first_m = (pid / per_group) * GROUP_M;
+		int gsz = min(p.tiles_m - first_m, GROUP_M);
+		tm0 = (first_m + (pid % per_group) % gsz) * BM; tn0 = ((pid % per_group) / gsz) * BN;
+	};
+	int m0, n0;   // origin of the tile being COMPUTED (the persistent variant fetches one tile ahead)
+	tile_origin(blockIdx.x, m0, n0);
 	const int k_begin = blockIdx.z * p.k_per_split;
 	const int k_end = min(p.K, k_begin + p.k_per_split);
 	const int nkt = (k_end - k_begin) / BK;
 
-	// Per-lane source pointers of this wave's DMA instructions for slab 0 (advance by BK per slab).
+	// Per-lane source pointers of this wave's DMA instructions for slab 0 of a tile (advance by BK per slab).
 	constexpr int A_NI = (AKC ? AI::NINST : BK * BM / 256) / NW;   // wave-instructions per wave per slab
 	constexpr int B_NI = (BKC ? BI::NINST : BK * BN / 256) / NW;
 	static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for the wave count");
 	const float* ga[A_NI];
 	const float* gb[B_NI];
-	size_t a_step, b_step;
-	if (AKC) {
+	const size_t a_step = AKC ? (size_t)BK : (size_t)BK * p.lda, b_step = BKC ? (size_t)BK : (size_t)BK * p.ldb;
+	auto open_tile = [&](int tm0, int tn0) {
+		if (AKC) {
 #pragma unroll
-		for (int i = 0; i < A_NI; i++) {
-			int inst = wave * A_NI + i;
-			int r = inst * AI::RPI + lane / AI::CPR, pos = lane % AI::CPR;
-			ga[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + k_begin + AI::swz(r, pos) * 4;   // swz is an involution
-		}
-		a_step = BK;
-	} else {  // A stored [k][m]: image [BK][BM]
+			for (int i = 0; i < A_NI; i++) {
+				int inst = wave * A_NI + i;
+				int r = inst * AI::RPI + lane / AI::CPR, pos = lane % AI::CPR;
+				ga[i] = p.A + (size_t)min(tm0 + r, p.M - 1) * p.lda + k_begin + AI::swz(r, pos) * 4;   // swz is an involution
+			}
+		} else {  // A stored [k][m]: image [BK][BM]
 #pragma unroll
-		for (int i = 0; i < A_NI; i++) {
-			int f = (wave * A_NI + i) * 64 + lane;   // chunk index in the image
-			int kr = f / (BM / 4), c = (f % (BM / 4)) * 4;
-			ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(m0 + c, p.M - 4);
+			for (int i = 0; i < A_NI; i++) {
+				int f = (wave * A_NI + i) * 64 + lane;   // chunk index in the image
+				int kr = f / (BM / 4), c = (f % (BM / 4)) * 4;
+				ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(tm0 + c, p.M - 4);
+			}
 		}
-		a_step = (size_t)BK * p.lda;
-	}
-	if (BKC) {
+		if (BKC) {
 #pragma unroll
-		for (int i = 0; i < B_NI; i++) {
-			int inst = wave * B_NI + i;
-			int r = inst * BI::RPI + lane / BI::CPR, pos = lane % BI::CPR;
-			gb[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + k_begin + BI::swz(r, pos) * 4;
-		}
-		b_step = BK;
-	} else {
+			for (int i = 0; i < B_NI; i++) {
+				int inst = wave * B_NI + i;
+				int r = inst * BI::RPI + lane / BI::CPR, pos = lane % BI::CPR;
+				gb[i] = p.B + (size_t)min(tn0 + r, p.N - 1) * p.ldb + k_begin + BI::swz(r, pos) * 4;
+			}
+		} else {
 #pragma unroll
-		for (int i = 0; i < B_NI; i++) {
-			int f = (wave * B_NI + i) * 64 + lane;
-			int kr = f / (BN / 4), c = (f % (BN / 4)) * 4;
-			gb[i] = p.B + (size_t)(k_begin + kr) * p.ldb + min(n0 + c, p.N - 4);
+			for (int i = 0; i < B_NI; i++) {
+				int f = (wave * B_NI + i) * 64 + lane;
+				int kr = f / (BN / 4), c = (f % (BN / 4)) * 4;
+				gb[i] = p.B + (size_t)(k_begin + kr) * p.ldb + min(tn0 + c, p.N - 4);
+			}
 		}
-		b_step = (size_t)BK * p.ldb;
-	}
+	};
+	open_tile(m0, n0);
 
 	typedef __attribute__((address_space(3))) void* lds_ptr_t;
 	typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -422,6 +425,104 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		__builtin_amdgcn_sched_barrier(0);
 	};
 
+	auto store_tile = [&]() {
+#pragma unroll
+		for (int im = 0; im < TM; im++)
+#pragma unroll
+			for (int in = 0; in < TN; in++) {
+				int col = n0 + wn0 + in * 32 + l31;
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+					if (row < p.M && col < p.N) {
+						if (p.splits > 1) p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[im][in][r];
+						else epilogue_store(p, row, col, acc[im][in][r]);
+					}
+				}
+			}
+	};
+
+	if constexpr (PERSIST) {
+		// Persistent variant: gridDim.x workgroups (two per CU) walk the tile list with stride gridDim.x and treat the K slabs
+		// of their consecutive tiles as ONE stream -- the DMA cursor runs two slabs ahead of the MFMAs straight across tile
+		// boundaries, so a new tile starts with its first slabs already in LDS, and the C stores of the finished tile drain
+		// under the next tile's MFMAs instead of in front of a fresh workgroup's cold prologue (a 4096^2 output cost a fixed
+		// 29 us that way).  Needs an even slab count per tile (fragment sets and LDS buffers alternate by slab parity).
+		static_assert(NBUF == 2, "persistent pipeline uses the two-buffer scheme");
+		const int total = p.tiles_m * p.tiles_n;
+		// DMA cursor: ga/gb walk the slabs of the tile being fetched; gan/gbn hold slab 0 of the tile after it (computed once per
+		// tile, outside the steps).  The switch is a select, not a branch: a branch between the fragment reads and their MFMAs
+		// makes hipcc wait for the reads and copy them at the join.
+		const float* gan[A_NI];
+		const float* gbn[B_NI];
+		int dma_left = nkt;
+		auto dma_next = [&](int buf) {
+			const bool sw = dma_left == 0;
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) ga[i] = sw ? gan[i] : ga[i];
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) gb[i] = sw ? gbn[i] : gb[i];
+			dma_left = (sw ? nkt : dma_left) - 1;
+			dma(buf);
+		};
+		auto plan_next = [&](int vb_next) {   // slab-0 pointers of the tile after the one being computed (past the end: this tile
+			int tm0, tn0;                      // again -- a harmless re-fetch into a buffer nobody reads)
+			tile_origin(vb_next < total ? vb_next : (int)blockIdx.x, tm0, tn0);
+			const float* sa[A_NI]; const float* sb[B_NI];
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) sa[i] = ga[i];
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) sb[i] = gb[i];
+			open_tile(tm0, tn0);
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) { gan[i] = ga[i]; ga[i] = sa[i]; }
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) { gbn[i] = gb[i]; gb[i] = sb[i]; }
+		};
+		float fa0[KK][TM][4], fb0[KK][TN][4], fa1[KK][TM][4], fb1[KK][TN][4];
+		// step on the slab in buffer `cur` (fragments in P): first MFMA group, wait + barrier, read the next slab of the stream
+		// into Q, fetch the slab after that into `cur`, remaining MFMAs
+		auto pstep = [&](int cur, float (&pa)[KK][TM][4], float (&pb)[KK][TN][4], float (&qa)[KK][TM][4], float (&qb)[KK][TN][4]) {
+			mfma_group(pa, pb, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			const float* As = lds + (cur ^ 1) * (A_SZ + B_SZ);
+#pragma unroll
+			for (int kk = 0; kk < KK; kk++) frags(As, As + A_SZ, kk, qa[kk], qb[kk]);
+			dma_next(cur);
+			__builtin_amdgcn_sched_barrier(0);
+			rest(pa, pb);
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		if (nkt > 0 && (int)blockIdx.x < total) {
+			dma_next(0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+#pragma unroll
+			for (int kk = 0; kk < KK; kk++) frags(lds, lds + A_SZ, kk, fa0[kk], fb0[kk]);
+			dma_next(1);
+			for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+				tile_origin(vb, m0, n0);
+				plan_next(vb + gridDim.x);
+				__builtin_amdgcn_sched_barrier(0);
+				for (int kt = 0; kt < nkt; kt += 2) {
+					pstep(0, fa0, fb0, fa1, fb1);
+					pstep(1, fa1, fb1, fa0, fb0);
+				}
+				store_tile();
+#pragma unroll
+				for (int i = 0; i < TM; i++)
+#pragma unroll
+					for (int j = 0; j < TN; j++)
+#pragma unroll
+						for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		return;
+	}
+
 	if constexpr (NBUF == 3) {
 		// Big-tile variant (256x128: half the DMA / barrier / LDS-read traffic per MFMA of the 128x128 tile, one residency
 		// round at 4096^3) under the 256-register budget of two waves per SIMD: only HALF a slab of fragments is
@@ -502,20 +603,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	}
 	}   // NBUF == 2
 
-#pragma unroll
-	for (int im = 0; im < TM; im++)
-#pragma unroll
-		for (int in = 0; in < TN; in++) {
-			int col = n0 + wn0 + in * 32 + l31;
-#pragma unroll
-			for (int r = 0; r < 16; r++) {
-				int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-				if (row < p.M && col < p.N) {
-					if (p.splits > 1) p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[im][in][r];
-					else epilogue_store(p, row, col, acc[im][in][r]);
-				}
-			}
-		}
+	if constexpr (!PERSIST) store_tile();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -755,6 +843,7 @@ static const Config kConfigs[] = {
 	{128, 64, 16, 256, true, "glds128x64x16"},
 	{128, 256, 16, 256, true, "glds128x256x16"},
 	{256, 128, 16, 256, true, "glds256x128x16"},
+	{128, 128, 16, 256, true, "glds128x128x16p"},   // persistent: 2 workgroups per CU walk the tile list, slab stream continuous across tiles
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -794,13 +883,13 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode
 #undef BLA_LAUNCH
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bool PERSIST = false>
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 	size_t lds_bytes = NBUF * (BM + BN) * BK * sizeof(float);
 	dim3 block(WM * WN * 64);
 #define BLA_LAUNCH(AK, BK_)                                                                                 \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF>;                          \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST>;                 \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -955,6 +1044,10 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 			if (splits > 32) splits = 32;
 		}
 	}
+	if (cfg == 10) {   // persistent variant: one pass over K per tile, slab parity must restart with every tile
+		BLA_REQUIRE(k % (2 * c.bk) == 0, BLA_ERR_INVALID, "gemm config 10 (%s) needs k %% %d == 0", c.name, 2 * c.bk);
+		splits = 1;
+	}
 	int kps = (k + splits - 1) / splits;
 	kps = (kps + c.bk - 1) / c.bk * c.bk;
 	if (kps == 0) kps = c.bk;
@@ -984,7 +1077,11 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		case 5: e = launch_glds<128, 128, 32, 2, 2>(a, akc, bkc, grid, s); break;
 		case 7: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 8: e = launch_glds<128, 256, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<256, 128, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;   // 9
+		case 9: e = launch_glds<256, 128, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;
+		default: {   // 10
+			unsigned tiles = grid.x, cap = 2u * (unsigned)cus;
+			e = launch_glds<128, 128, 16, 2, 2, 1, 2, true>(a, akc, bkc, dim3(tiles < cap ? tiles : cap, 1, 1), s);
+		} break;
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};

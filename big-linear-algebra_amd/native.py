@@ -68,6 +68,7 @@ SIGNATURES = {
     "bla_reshape_channels_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I]), "bla_reshape_matrix_channels_f32": (_I, [_VP, _VP, _VP, _I, _I]),
     "bla_conv_forward_f32": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f32": (_I, [_VP] * 9 + [_I] * 6),
     "bla_conv2d_forward_f32": (_I, [_VP] * 4 + [_I] * 6), "bla_conv2d_backward_f32": (_I, [_VP] * 7 + [_I] * 6),
+    "bla_conv2d_forward_batched_f32": (_I, [_VP] * 4 + [_I] * 7), "bla_conv2d_backward_batched_f32": (_I, [_VP] * 7 + [_I] * 7),
     "bla_group_norm_f32": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f32": (_I, [_VP] * 6 + [_I] * 3),
     "bla_relu_mask_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]), "bla_dropout_f32": (_I, [_VP, _VP, _VP, _VP, _SZ]),
     "bla_dropout_mask_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_nearest_neighbours_f32": (_I, [_VP, _VP, _VP] + [_I] * 6),

@@ -176,6 +176,13 @@ BLA_API bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, con
 BLA_API bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride);
 BLA_API bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern,
                                            float* d_del_x, float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride);
+/* `batch` images through the same kernels in one launch (the reference has no batch dimension: one conv() / conv_ddx() call
+ * per image, model/cifar_unet.c:1105-1165).  x [B][C][H][W], out / del_y [B][F][Ho][Wo], del_x [B][C][H][W];
+ * del_kern = SUM over the images of the per-image weight gradient, folded in image order. */
+BLA_API bla_status bla_conv2d_forward_batched_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k,
+                                                  int c_in, int f_n, int stride);
+BLA_API bla_status bla_conv2d_backward_batched_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern,
+                                                   float* d_del_x, float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride);
 /* group_norm / group_norm_ddx, lib/norm.c:5-93, on [C][H*W]; quirk Q3 kept (epsilon == 0, "stdevs" holds the variance,
  * out = (x - mean) / variance).  Note the reference's argument orders (lib/norm.h:6-7). */
 BLA_API bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw);

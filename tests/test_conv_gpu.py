@@ -154,3 +154,36 @@ def test_implicit_gemm_conv_matches_reference(dev, ora):
             keep = dev.empty((cin, h, w))
             assert dev.lib().bla_conv2d_backward_f32(None, dev.to_device(del_y).ptr, dx_.ptr, dk_.ptr, None, keep.ptr, keep.ptr,
                                                      h, w, k, cin, cout, s) == 5                # data gradient: undefined (Q5)
+
+
+@pytest.mark.parametrize("batch", [2, 5, 33])
+def test_batched_conv_equals_per_image_calls(dev, ora, batch):
+    """bla_conv2d_*_batched: every image's output and data gradient bit-identical to the single-image entry point
+    (same kernel, same K order; the image index only offsets pointers), the weight gradient = the per-image gradients
+    summed, checked against the oracle's per-image conv_ddx."""
+    for ci, (h, w, cin, cout, k, s) in enumerate([(8, 8, 3, 4, 3, 1), (7, 9, 2, 3, 3, 2), (16, 16, 32, 24, 3, 1)]):
+        ho, wo = ora.out_hw(h, w, s)
+        x = uniform(500 + ci, (batch, cin, h, w), -1, 1, F32); kern = uniform(600 + ci, (cout, cin, k, k), -0.3, 0.3, F32)
+        del_y = uniform(700 + ci, (batch, cout, ho, wo), -1, 1, F32)
+        dx_, dk_, dy_ = dev.to_device(x), dev.to_device(kern), dev.to_device(del_y)
+        out = dev.empty((batch, cout, ho, wo)).fill_bytes(0xFF)
+        call(dev, "bla_conv2d_forward_batched_f32", dx_, dk_, out, batch, h, w, k, cin, cout, s)
+        got = out.numpy()
+        dkern = dev.empty((cout, cin, k, k)).fill_bytes(0xFF)
+        dxx = dev.empty((batch, cin, h, w)).fill_bytes(0xFF) if s == 1 else None
+        scratch = dev.empty((cout * cin * k * k,)) if s == 1 else None
+        call(dev, "bla_conv2d_backward_batched_f32", dy_, dx_, dk_, dkern, dxx, scratch, batch, h, w, k, cin, cout, s)
+        want_dk = np.zeros((cout, cin, k, k)); bound_dk = 0.0
+        for b in range(batch):
+            one = dev.empty((cout, ho, wo)); xb = dev.to_device(x[b])
+            call(dev, "bla_conv2d_forward_f32", xb, dk_, one, h, w, k, cin, cout, s)
+            assert np.array_equal(got[b], one.numpy()), (ci, b)
+            fw = ora.conv_intended(x[b].astype(np.float64), kern.astype(np.float64), s)
+            dq = ora.reshape_matrix_channels(del_y[b].astype(np.float64))
+            want_dk += ora.matrix_to_kernels(ora.matmul(ora.transpose(fw["im2col"]), dq), cin, k)
+            bound_dk += (np.abs(fw["im2col"]).T @ np.abs(dq)).max()
+            if s == 1:
+                d1 = dev.empty((cin, h, w)); dk1 = dev.empty((cout, cin, k, k))
+                call(dev, "bla_conv2d_backward_f32", dev.to_device(del_y[b]), xb, dk_, dk1, d1, scratch, h, w, k, cin, cout, 1)
+                assert np.array_equal(dxx.numpy()[b], d1.numpy()), (ci, b)
+        assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk).all(), ci

@@ -59,7 +59,7 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
@@ -71,7 +71,7 @@ def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     if 3 <= cfg <= 5 or cfg >= 7:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
                   (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128)]
-        if cfg == 5:
+        if cfg in (5, 10):   # BK = 32, or the persistent kernel's even slab count
             shapes = [s for s in shapes if s[1] % 32 == 0]
     try:
         for j, (m, k, n) in enumerate(shapes):
@@ -81,6 +81,30 @@ def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
             check_gemm(ora, c, a.T if ta else a, b.T if tb else b, tag=f"cfg{cfg} ta{ta} tb{tb} {m}x{k}x{n}")
     finally:
         dev.lib().bla_gemm_set_config(-1, 0)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
+def test_persistent_kernel_many_tiles_per_workgroup(dev, ta, tb):
+    """Config 10 walks several tiles per workgroup once there are more tiles than 2 x CUs: 25 x 25 tiles with ragged
+    edges here, so the slab stream crosses tile boundaries (prefetch of the next tile under the current one's tail,
+    stores of the finished tile under the next one's MFMAs).  Checked against a float64 product."""
+    m, k, n = 3100, 96, 3148   # extents % 4 == 0 (16-byte DMA granules), not multiples of the tile
+    a = uniform(31, (k, m) if ta else (m, k), dtype=np.float32)
+    b = uniform(32, (n, k) if tb else (k, n), dtype=np.float32)
+    dev.lib().bla_gemm_set_config(10, 0)
+    try:
+        da, db = dev.to_device(a), dev.to_device(b)
+        c = dev.zeros((m, n))
+        dev.gemm(da, db, c, transa=bool(ta), transb=bool(tb))
+        assert "glds128x128x16p" in dev.lib().bla_gemm_last_kernel().decode()
+        got = c.numpy()
+    finally:
+        dev.lib().bla_gemm_set_config(-1, 0)
+    A = (a.T if ta else a).astype(np.float64); B = (b.T if tb else b).astype(np.float64)
+    ref = A @ B
+    bound = np.abs(A) @ np.abs(B)
+    assert np.all(np.abs(got - ref) <= 1e-5 * bound + 1e-30)
+    assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref)
 
 
 @pytest.mark.parametrize("split", [2, 3, 7])

@@ -45,3 +45,19 @@ for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256
             t0 = time.perf_counter(); oracle.conv_ddx_intended(rng.uniform(-1, 1, (cout, ho, ho)), fw["im2col"], fw["kmat"], cin, k); tcb = time.perf_counter() - t0
             line += f" bwd {tcb*1e3:7.1f} ms"
     print(line, flush=True)
+
+# batch of 64 images through the same kernels (SURVEY 8(d) cfg 5: "batch-of-64 images (M x 64)"): one launch per pass
+print("\nbatch of 64 images, implicit-GEMM path (one launch per pass; FLOPs = 64 x the single-image figure)", flush=True)
+B = 64
+for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256, 256, 3, 1), (32, 128, 256, 3, 2)]:
+    w = h; ho = -(-h // s); hw = ho * ho; kkc = k * k * cin
+    x = bla.to_device(rng.uniform(-1, 1, (B, cin, h, w)).astype(np.float32)); kern = bla.to_device(rng.uniform(-.1, .1, (cout, cin, k, k)).astype(np.float32))
+    dy = bla.to_device(rng.uniform(-1, 1, (B, cout, ho, ho)).astype(np.float32))
+    out, dk, dx, scr = bla.empty((B, cout, ho, ho)), bla.empty((cout, cin, k, k)), bla.empty((B, cin, h, w)), bla.empty((cout * kkc,))
+    fl = 2.0 * hw * kkc * cout * B
+    t_f = timeit(lambda: chk(L.bla_conv2d_forward_batched_f32(st, x.ptr, kern.ptr, out.ptr, B, h, w, k, cin, cout, s)), iters=10)
+    line = f"{cin:>3}->{cout:<3} {h}x{h} k{k} s{s} x{B}  fwd {t_f*1e6:8.1f} us ({fl/t_f/1e12:6.2f} TF/s, {fl/t_f/1e12/157.3*100:4.1f}% of fp32 MFMA peak)"
+    if s == 1:
+        t_b = timeit(lambda: chk(L.bla_conv2d_backward_batched_f32(st, dy.ptr, x.ptr, kern.ptr, dk.ptr, dx.ptr, scr.ptr, B, h, w, k, cin, cout, 1)), iters=10)
+        line += f"   bwd (dkern + dx) {t_b*1e6:8.1f} us ({2*fl/t_b/1e12:6.2f} TF/s)"
+    print(line, flush=True)
