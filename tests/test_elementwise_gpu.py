@@ -74,7 +74,7 @@ def test_golden_matrix_ops(dev, ora):
         d = dev.to_device(a * 4); call(dev, "bla_softmax_rows_f32", d, r, c); close(d.numpy(), g[f"s{i}_softmax_rows"], rtol=1e-5, scale=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 1000), (1000, 1), (257, 129), (784, 256), (2048, 3000)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 1000), (1000, 1), (257, 129), (784, 256), (2048, 3000), (300, 9000), (515, 4100), (64, 36000)])
 def test_larger_shapes_vs_oracle(dev, ora, shape):
     r, c = shape; n = r * c
     a = uniform(1, shape, -3, 3, np.float32); b = uniform(2, shape, -3, 3, np.float32)
@@ -106,11 +106,12 @@ def test_unaligned_views_and_empty(dev):
     assert np.array_equal(d.numpy(), want)
 
 
-def test_softmax_grad_fused(dev, ora):
-    z = uniform(1, (10, 300), -4, 4, np.float32)
-    y = np.zeros((10, 300), np.float32); y[np.arange(300) % 10, np.arange(300)] = 1
-    d = dev.to_device(z); g = dev.empty((10, 300))
-    call(dev, "bla_softmax_cols_grad_f32", d, 10, 300, dev.to_device(y), 1 / 784, g)
+@pytest.mark.parametrize("rows,cols", [(10, 300), (300, 260)])   # strided kernel / streaming three-launch path
+def test_softmax_grad_fused(dev, ora, rows, cols):
+    z = uniform(1, (rows, cols), -4, 4, np.float32)
+    y = np.zeros((rows, cols), np.float32); y[np.arange(cols) % rows, np.arange(cols)] = 1
+    d = dev.to_device(z); g = dev.empty((rows, cols))
+    call(dev, "bla_softmax_cols_grad_f32", d, rows, cols, dev.to_device(y), 1 / 784, g)
     p = ora.softmax_cols(z.astype(np.float64))
     close(d.numpy(), p, rtol=1e-5, scale=1e-6)
     close(g.numpy(), ora.scale(ora.add(p, -y.astype(np.float64)), 1 / 784), rtol=1e-5, scale=1e-8)
