@@ -85,6 +85,18 @@ __global__ void __launch_bounds__(kThreads) tile_columns_kernel(float* __restric
 	}
 }
 
+// bias column (b_cols == 1), 16 bytes per lane: flat walk over float4 groups, one divide per group for the row
+__global__ void __launch_bounds__(kThreads) bias_column_vec_kernel(float* __restrict__ a, const float* __restrict__ b, int rows, int cols) {
+	const unsigned c4 = (unsigned)cols / 4;
+	const size_t n4 = (size_t)rows * c4;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+		float v = b[i / c4];
+		float4 x = reinterpret_cast<float4*>(a)[i];
+		x.x += v; x.y += v; x.z += v; x.w += v;
+		reinterpret_cast<float4*>(a)[i] = x;
+	}
+}
+
 __global__ void __launch_bounds__(kThreads) tile_rows_kernel(float* __restrict__ a, const float* __restrict__ b, int rows, int cols) {
 	size_t n = (size_t)rows * cols;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i % cols];
@@ -535,6 +547,11 @@ bla_status bla_add_tile_columns_f32(void* stream, float* d_a, int a_rows, int a_
 	BLA_REQUIRE(a_rows >= 0 && a_cols >= 0 && b_cols > 0, BLA_ERR_INVALID, "bad shape %dx%d tiled by %d columns", a_rows, a_cols, b_cols);
 	if (a_rows == 0 || a_cols == 0) return BLA_OK;
 	BLA_REQUIRE(d_a && d_b, BLA_ERR_INVALID, "null operand");
+	if (b_cols == 1 && a_cols % 4 == 0 && (uintptr_t)d_a % 16 == 0) {
+		hipLaunchKernelGGL(bias_column_vec_kernel, dim3(grid_for((size_t)a_rows * (a_cols / 4))), dim3(kThreads), 0, pick_stream(stream), d_a, d_b, a_rows, a_cols);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
+	}
 	unsigned gx = (unsigned)((a_cols + kThreads - 1) / kThreads);
 	if (gx > 64) gx = 64;
 	unsigned gy = (unsigned)a_rows;
