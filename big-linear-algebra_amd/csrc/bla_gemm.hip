@@ -614,21 +614,31 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 // once at the end and are summed in wave order (deterministic), and the epilogue is fused -- no slab
 // kernel, no second launch.  K-contiguous operands load 16 B per lane (row l&31, k-half l>>5),
 // row-contiguous operands four coalesced dwords per lane.
+constexpr int kWskLdsFloats = 4 * 2 * 2 * 32 * 32;   // [wave][set][operand][32 k][32]
+struct WskShared {   // the LDS of one workgroup, declared once by the kernel (the pair kernel runs either body on it)
+	float smem[kWskLdsFloats];
+	float red_rs[4][64];
+	int is_last;
+};
+
+// bx = tile index (row-major over tiles_m x tiles_n), by = K-split index (0 when splits == 1)
 template <bool AKC, bool BKC, bool AVEC, bool BVEC>
-__global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
+__device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by, WskShared& sh) {
 	constexpr int NW = 4;  // one wave per SIMD: a CU retires 256 fp32-MFMA FLOP/clk however many waves it hosts (8 / 16 measured slower)
 	constexpr int PF = 4;  // k-groups (8 k each) per half-chunk = 32 k; two half-chunks (register sets) are in flight
 	// One LDS array: per-wave staging of row-contiguous operands during the K loop ([wave][set][operand][32 k][32]),
 	// the cross-wave reduction afterwards.
-	__shared__ __attribute__((aligned(16))) float smem[NW * 2 * 2 * 32 * 32];
+	float* smem = sh.smem;
 	float (*red)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem);
+	float (*red_rs)[64] = sh.red_rs;
+	int& is_last = sh.is_last;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l31 = lane & 31, h = lane >> 5;
-	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+	const int tile_m = bx / p.tiles_n, tile_n = bx % p.tiles_n;
 	const int m0 = tile_m * 32, n0 = tile_n * 32;
-	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8; a workgroup covers 4*kw, blockIdx.y selects which
-	const int blk_end = min(p.K, (int)(blockIdx.y + 1) * NW * kw);
-	const int k_begin = min(blk_end, ((int)blockIdx.y * NW + wave) * kw), k_end = min(blk_end, k_begin + kw);
+	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8; a workgroup covers 4*kw, by selects which
+	const int blk_end = min(p.K, (by + 1) * NW * kw);
+	const int k_begin = min(blk_end, (by * NW + wave) * kw), k_end = min(blk_end, k_begin + kw);
 	const int arow = min(m0 + l31, p.M - 1), bcol = min(n0 + l31, p.N - 1);  // clamped: out-of-range rows/cols are never stored
 	float* stage = smem + wave * (2 * 2 * 32 * 32);   // [set][operand][32 k][32]
 
@@ -668,7 +678,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 	};
 
 #ifdef BLA_WSK_DIAG   // diagnostics build only (tools/wsk_stamps.py): s_memtime stamps of workgroup 0, wave 0
-#define BLA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (p.stamps) p.stamps[i] = t_; } } while (0)
+#define BLA_STAMP(i) do { if (bx == 0 && by == 0 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (p.stamps) p.stamps[i] = t_; } } while (0)
 #else
 #define BLA_STAMP(i) do {} while (0)
 #endif
@@ -736,7 +746,6 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 	// partial tiles -> LDS (stride 33: the C/D map writes 32 consecutive columns per register), sum in wave order
 #pragma unroll
 	for (int r = 0; r < 16; r++) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
-	__shared__ float red_rs[4][64];
 	if (want_rs) red_rs[wave][lane] = rs;
 	__syncthreads();
 	if (want_rs && tid < 32 && m0 + tid < p.M) {
@@ -746,14 +755,13 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 		p.row_sum_a[m0 + tid] = t;
 	}
 	if (p.splits > 1) {
-		// K is also cut over blockIdx.y (few tiles, long K: otherwise most CUs idle).  Each workgroup publishes its partial
+		// K is also cut over by (few tiles, long K: otherwise most CUs idle).  Each workgroup publishes its partial
 		// tile, draws a ticket on the tile's counter, and the LAST arriver folds the partials in split order (deterministic)
 		// and runs the epilogue -- no slab kernel, no second launch.  Hand-off per cdna_hip_programming.md "In-launch split-K
 		// reduction": plain stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 agent release fence -> vmcnt(0) ->
 		// relaxed agent fetch_add; last arriver: agent acquire fence -> vmcnt(0) -> barrier -> plain loads.  Correct for any
 		// placement of a tile's workgroups over CUs / XCDs.
-		__shared__ int is_last;
-		float* mine = p.slab + ((size_t)blockIdx.x * p.splits + blockIdx.y) * 1024;
+		float* mine = p.slab + ((size_t)bx * p.splits + by) * 1024;
 		for (int e = tid; e < 1024; e += NW * 64) {
 			float s = 0.f;
 #pragma unroll
@@ -765,17 +773,17 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 		if (tid == 0) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			unsigned ticket = __hip_atomic_fetch_add(&p.counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			unsigned ticket = __hip_atomic_fetch_add(&p.counters[bx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			is_last = ticket == (unsigned)p.splits - 1;
 			if (is_last) {
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__hip_atomic_store(&p.counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+				__hip_atomic_store(&p.counters[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 			}
 		}
 		__syncthreads();
 		if (!is_last) return;
-		const float* all = p.slab + (size_t)blockIdx.x * p.splits * 1024;
+		const float* all = p.slab + (size_t)bx * p.splits * 1024;
 		for (int e = tid; e < 1024; e += NW * 64) {
 			int r = e >> 5, c = e & 31;
 			float s = 0.f;
@@ -819,6 +827,22 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 			p.softmax_grad[(size_t)r * p.ldc + col] = (pr - p.softmax_y[(size_t)r * p.ldc + col]) * p.softmax_scale;
 		}
 	}
+}
+
+template <bool AKC, bool BKC, bool AVEC, bool BVEC>
+__global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
+	__shared__ __attribute__((aligned(16))) WskShared sh;
+	wsk_body<AKC, BKC, AVEC, BVEC>(p, (int)blockIdx.x, (int)blockIdx.y, sh);
+}
+
+// Two independent latency-bound products in ONE launch: workgroups [0, tiles_p) run product p, the rest product q.  In the
+// MNIST-NN backward pass dW_l = dZ_l . A_{l-1}^T (NT) and dZ_{l-1} = W_l^T . dZ_l (TN) both depend only on dZ_l: launched
+// together they overlap instead of queueing, which takes two ~5 us launches off the step's critical path.
+template <bool AKC1, bool BKC1, bool AKC2, bool BKC2>
+__global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, GemmArgs q, int tiles_p) {
+	__shared__ __attribute__((aligned(16))) WskShared sh;
+	if ((int)blockIdx.x < tiles_p) wsk_body<AKC1, BKC1, true, true>(p, (int)blockIdx.x, 0, sh);
+	else wsk_body<AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
 }
 
 // Sums the split-K slabs in split order (deterministic) and applies the epilogue.
@@ -932,9 +956,17 @@ bla_status bla_gemm_set_config(int config, int split_k) {
 
 const char* bla_gemm_last_kernel(void) { return g_last_kernel; }
 
-bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,
-                        const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                        const bla_gemm_epilogue* ep) {
+}  // extern "C"
+
+namespace {
+struct WskPlan { GemmArgs a; bool akc, bkc, valid; };
+}
+
+// plan != nullptr: a product that resolves to the un-split, fully vectorised wave-split-K kernel is NOT launched but handed
+// back (plan->valid) so that bla_gemm_pair_f32 can put two of them into one launch; anything else launches as usual.
+static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, int k,
+                            const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                            const bla_gemm_epilogue* ep, WskPlan* plan) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(m >= 0 && n >= 0 && k >= 0, BLA_ERR_INVALID, "negative dimension m=%d n=%d k=%d", m, n, k);
@@ -1015,6 +1047,7 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		const bool avec = a_al && (akc ? (k % 4 == 0 && k >= 4) : (m % 4 == 0 && m >= 4));
 		const bool bvec = b_al && (bkc ? (k % 4 == 0 && k >= 4) : (n % 4 == 0 && n >= 4));
 		dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)ksplit);
+		if (plan && ksplit == 1 && avec && bvec) { plan->a = a; plan->akc = akc; plan->bkc = bkc; plan->valid = true; return BLA_OK; }
 		hipError_t e = launch_wsk(a, akc, bkc, avec, bvec, grid, s);
 		if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk_kernel launch");
 		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s%s_ksplit%d", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n',
@@ -1096,6 +1129,39 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 		if (e != hipSuccess) return hip_fail(e, "gemm_splitk_reduce_kernel launch");
 	}
 	if (deferred_row_sum) return window_sum(stream, A, m, k, lda, deferred_row_sum);
+	return BLA_OK;
+}
+
+extern "C" {
+
+bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,
+                        const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        const bla_gemm_epilogue* ep) {
+	return gemm_impl(stream, transa, transb, m, n, k, A, lda, B, ldb, C, ldc, ep, nullptr);
+}
+
+/* Two INDEPENDENT products (neither reads what the other writes) issued together.  When both are latency-bound shapes of the
+ * wave-split-K kernel they share one launch and overlap; otherwise this is two bla_gemm_f32 calls. */
+bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q) {
+	BLA_REQUIRE(p && q, BLA_ERR_INVALID, "null descriptor");
+	WskPlan pp = {}, pq = {};
+	const bool try_pair = g_force_config < 0 && g_force_split <= 0;
+	bla_status st = gemm_impl(stream, p->transa, p->transb, p->m, p->n, p->k, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, p->ep, try_pair ? &pp : nullptr);
+	if (st) return st;
+	st = gemm_impl(stream, q->transa, q->transb, q->m, q->n, q->k, q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->ep, pp.valid ? &pq : nullptr);
+	if (st) return st;
+	hipStream_t s = pick_stream(stream);
+	const int tp = pp.valid ? pp.a.tiles_m * pp.a.tiles_n : 0, tq = pq.valid ? pq.a.tiles_m * pq.a.tiles_n : 0;
+	hipError_t e = hipSuccess;
+	if (pp.valid && pq.valid && pp.akc && pp.bkc && !pq.akc && !pq.bkc && !pp.a.softmax_grad && !pq.a.softmax_grad) {   // NT beside TN (dW_l beside dZ_{l-1})
+		hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<true, true, false, false>), dim3((unsigned)(tp + tq)), dim3(256), 0, s, pp.a, pq.a, tp);
+		e = hipGetLastError();
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_nt+tn_%d+%d", tp, tq);
+	} else {
+		if (pp.valid) e = launch_wsk(pp.a, pp.akc, pp.bkc, true, true, dim3((unsigned)tp, 1), s);
+		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);
+	}
+	if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk pair launch");
 	return BLA_OK;
 }
 

@@ -189,18 +189,28 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	// (Measured and not kept: running the layer-3 / layer-2 weight-gradient products on a side stream -- parallel branches of
 	// the captured graph -- to take two launches off the critical path.  The cross-queue dependencies cost more than the
 	// launches: 69.6 us per step instead of 56.)
+	// dW_l = dZ_l . A_{l-1}^T and dZ_{l-1} = (W_l^T . dZ_l) (.) relu'(Z_{l-1}) both depend only on dZ_l: issued as a pair they share
+	// one launch (the reference runs them one after the other, :267-289).
 	bla_gemm_epilogue eg = {};
 	eg.alpha = 1.f; eg.row_sum_a = fuse_db ? db3 : nullptr;
-	st = bla_gemm_f32(s, 0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, &eg); if (st) return st;         // dW3 = dZ3 . A2^T, :267-270; db3 :271
-	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st; }
 	bla_gemm_epilogue em = {};
 	em.alpha = 1.f; em.relu_mask = nn->z2; em.ld_mask = B;
-	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st;         // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278
-	eg.row_sum_a = fuse_db ? db2 : nullptr;
-	st = bla_gemm_f32(s, 0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &eg); if (st) return st;         // :279-282
+	{
+		bla_gemm_desc dw = {0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, &eg};       // dW3 = dZ3 . A2^T, :267-270; db3 :271
+		bla_gemm_desc dz = {1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em};       // dZ2, :273-278
+		st = bla_gemm_pair_f32(s, &dw, &dz); if (st) return st;
+	}
+	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st; }
+	bla_gemm_epilogue eg2 = {};
+	eg2.alpha = 1.f; eg2.row_sum_a = fuse_db ? db2 : nullptr;
+	bla_gemm_epilogue em1 = {};
+	em1.alpha = 1.f; em1.relu_mask = nn->z1; em1.ld_mask = B;
+	{
+		bla_gemm_desc dw = {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &eg2};      // dW2, :279-282
+		bla_gemm_desc dz = {1, 0, n1, B, n2, W2, n1, nn->dz2, B, nn->dz1, B, &em1};      // dZ1, :284-289
+		st = bla_gemm_pair_f32(s, &dw, &dz); if (st) return st;
+	}
 	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st; }
-	em.relu_mask = nn->z1;
-	st = bla_gemm_f32(s, 1, 0, n1, B, n2, W2, n1, nn->dz2, B, nn->dz1, B, &em); if (st) return st;         // :284-289
 	eg.alpha = xs; eg.row_sum_a = fuse_db ? db1 : nullptr;
 	st = bla_gemm_f32(s, 0, 1, n1, n0, B, nn->dz1, B, d_x_raw, B, dW1, n0, &eg); if (st) return st;        // :290-293
 	if (!fuse_db) { st = bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode); if (st) return st; }

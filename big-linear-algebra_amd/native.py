@@ -25,6 +25,13 @@ class Epilogue(C.Structure):
                 ("softmax_grad", C.c_void_p)]
 
 
+class GemmDesc(C.Structure):
+    """struct bla_gemm_desc (include/bla.h): one product of a bla_gemm_pair_f32 call."""
+    _fields_ = [("transa", C.c_int), ("transb", C.c_int), ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+                ("ep", C.POINTER(Epilogue))]
+
+
 class AttentionWs(C.Structure):
     """struct bla_attention_ws (include/bla.h): six device pointers."""
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "scores_raw", "weights", "attention")]
@@ -83,6 +90,7 @@ SIGNATURES = {
     "bla_mnist_nn_get_params": (_I, [_VP, _VP]), "bla_mnist_nn_activation": (_I, [_VP, _I, C.POINTER(_VP), C.POINTER(_I)]),
     "bla_mnist_nn_forward_backward": (_I, [_VP, _VP, _VP, _VP, _I]), "bla_mnist_nn_apply": (_I, [_VP, _VP, _F]),
     "bla_mnist_nn_train_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]), "bla_mnist_nn_graph_step": (_I, [_VP, _VP, _F, _I, _I]),
+    "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]),
     "bla_dp_create": (_I, [C.POINTER(_VP), _I, _I, C.c_size_t]), "bla_dp_destroy": (_I, [_VP]),
     "bla_dp_export": (_I, [_VP, _VP]), "bla_dp_connect": (_I, [_VP, _VP]),
     "bla_dp_bucket": (_VP, [_VP, _I]), "bla_dp_count": (C.c_size_t, [_VP]),
@@ -199,6 +207,19 @@ def _ptr(x):
     if x is None:
         return None
     return x.ptr if isinstance(x, DeviceArray) else int(x)
+
+
+def gemm_desc(a, b, c, transa=False, transb=False, epilogue=None):
+    """Descriptor for gemm_pair: op(A) op(B) -> C on device arrays; `epilogue` is an Epilogue (kept alive by the caller)."""
+    m = a.shape[1] if transa else a.shape[0]
+    k = a.shape[0] if transa else a.shape[1]
+    n = b.shape[0] if transb else b.shape[1]
+    return GemmDesc(int(transa), int(transb), m, n, k, a.ptr, a.ld, b.ptr, b.ld, c.ptr, c.ld,
+                    C.pointer(epilogue) if epilogue is not None else None)
+
+
+def gemm_pair(p, q, stream=None):
+    check(lib().bla_gemm_pair_f32(stream, C.byref(p), C.byref(q)))
 
 
 def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None, bias_col=None, pre_act=None,

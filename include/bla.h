@@ -117,6 +117,17 @@ typedef struct bla_gemm_epilogue {
 BLA_API bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,
                         const float* d_a, int lda, const float* d_b, int ldb,
                         float* d_c, int ldc, const bla_gemm_epilogue* ep /* NULL = plain product */);
+/* Two independent products (neither reads what the other writes) issued together: when both are latency-bound shapes they
+ * share one launch and overlap -- dW_l = dZ_l.A^T beside dZ_{l-1} = W_l^T.dZ_l in model/mnist_nn.c:267-289, which the
+ * reference runs one after the other.  Otherwise identical to two bla_gemm_f32 calls. */
+typedef struct bla_gemm_desc {
+	int transa, transb, m, n, k;
+	const float* A; int lda;
+	const float* B; int ldb;
+	float* C; int ldc;
+	const bla_gemm_epilogue* ep;   /* may be NULL */
+} bla_gemm_desc;
+BLA_API bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q);
 
 /* Tuning/diagnostics: force a tile configuration (-1 = automatic) and split-K factor (0 = automatic). */
 BLA_API bla_status bla_gemm_set_config(int config, int split_k);

@@ -252,3 +252,32 @@ def test_wave_split_k_with_in_launch_fold(dev, ora, split):
             assert (np.abs(outs[0] - ora.relu(zr)) <= RTOL * bound).all()
     finally:
         dev.lib().bla_gemm_set_config(-1, 0)
+
+
+def test_gemm_pair_shares_one_launch(dev, ora):
+    """bla_gemm_pair_f32: an NT product beside a TN product (dW_l beside dZ_{l-1} of model/mnist_nn.c:267-289) in one launch,
+    both with their epilogues (row sums of A / relu' mask); other combinations fall back to two launches.  Same results either way."""
+    nat = dev.native
+    for (m1, n1, k1, m2, n2, k2) in [(10, 128, 256, 128, 256, 10), (128, 256, 256, 256, 256, 128), (33, 40, 64, 70, 36, 33)]:
+        a1 = uniform(1, (m1, k1), dtype=np.float32); b1 = uniform(2, (n1, k1), dtype=np.float32)      # NT: A [m][k], B [n][k]
+        a2 = uniform(3, (k2, m2), dtype=np.float32); b2 = uniform(4, (k2, n2), dtype=np.float32)      # TN: A [k][m], B [k][n]
+        z = uniform(5, (m2, n2), dtype=np.float32)
+        d = [dev.to_device(x) for x in (a1, b1, a2, b2, z)]
+        c1, c2, rs = dev.zeros((m1, n1)), dev.zeros((m2, n2)), dev.zeros((m1,))
+        e1 = nat.Epilogue(1.0, 0.0, None, None, None, 0, 0, None, 0, rs.ptr, None, 0.0, None)
+        e2 = nat.Epilogue(1.0, 0.0, None, None, None, 0, 0, d[4].ptr, n2, None, None, 0.0, None)
+        p = nat.gemm_desc(d[0], d[1], c1, transb=True, epilogue=e1)
+        q = nat.gemm_desc(d[2], d[3], c2, transa=True, epilogue=e2)
+        nat.gemm_pair(p, q)
+        name = dev.lib().bla_gemm_last_kernel().decode()
+        check_gemm(ora, c1.numpy(), a1, b1.T, tag=f"pair NT {m1}x{k1}x{n1} ({name})")
+        want2 = (a2.T.astype(np.float64) @ b2.astype(np.float64)) * (z > 0)
+        bound = np.abs(a2.T).astype(np.float64) @ np.abs(b2).astype(np.float64)
+        assert np.all(np.abs(c2.numpy() - want2) <= 1e-5 * bound + 1e-30), name
+        np.testing.assert_allclose(rs.numpy(), a1.astype(np.float64).sum(1), rtol=1e-5, atol=1e-5)
+    # aligned shapes of the trainer do share the launch
+    a1 = dev.to_device(uniform(1, (128, 256), dtype=np.float32)); b1 = dev.to_device(uniform(2, (256, 256), dtype=np.float32))
+    a2 = dev.to_device(uniform(3, (128, 256), dtype=np.float32)); b2 = dev.to_device(uniform(4, (128, 256), dtype=np.float32))
+    c1, c2 = dev.zeros((128, 256)), dev.zeros((256, 256))
+    nat.gemm_pair(nat.gemm_desc(a1, b1, c1, transb=True), nat.gemm_desc(a2, b2, c2, transa=True))
+    assert "pair_nt+tn" in dev.lib().bla_gemm_last_kernel().decode()
