@@ -347,9 +347,113 @@ static bla_status get_table(hipStream_t s, const ConvGeom& g, const int2** out) 
 	return BLA_OK;
 }
 
+// per-geometry table of the output pixels: r = i*Wo + j -> {(i*s)*W + j*s, (i*s) | (j*s) << 16}
+__global__ void __launch_bounds__(256) conv_pixel_table_kernel(int2* tab, ConvGeom g) {
+	int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= g.ho * g.wo) return;
+	int i = r / g.wo, j = r - i * g.wo;
+	tab[r] = make_int2(i * g.s * g.w + j * g.s, ((i * g.s) & 0xffff) | ((j * g.s) << 16));
+}
+
+struct PixelTableEntry { int w, s, ho, wo; int2* tab; };
+static PixelTableEntry g_ptables[64];
+static int g_num_ptables = 0;
+
+static bla_status get_pixel_table(hipStream_t s, const ConvGeom& g, const int2** out) {
+	for (int i = 0; i < g_num_ptables; i++) {
+		const PixelTableEntry& t = g_ptables[i];
+		if (t.w == g.w && t.s == g.s && t.ho == g.ho && t.wo == g.wo) { *out = t.tab; return BLA_OK; }
+	}
+	BLA_REQUIRE(g_num_ptables < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	int n = g.ho * g.wo;
+	int2* tab;
+	BLA_HIP(hipMalloc((void**)&tab, (size_t)n * sizeof(int2)));
+	hipLaunchKernelGGL(conv_pixel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, g);
+	BLA_HIP(hipGetLastError());
+	g_ptables[g_num_ptables++] = PixelTableEntry{g.w, g.s, g.ho, g.wo, tab};
+	*out = tab;
+	return BLA_OK;
+}
+
+// ---- stride-1 forward on a zero-padded copy ------------------------------------------------------------------------
+// dst [B*C][H+k-1][W+k-1] = src [B*C][H][W] surrounded by the SAME padding; one pass (33 MB for 64 x 128 x 32 x 32), after which
+// the gather needs no bounds checks and four consecutive output pixels of a row are four consecutive floats.  (The 16-byte DMAs
+// are mostly unaligned -- tap column q shifts the address by q floats and the pitch W+k-1 is even but rarely a multiple of 4;
+// forcing them aligned in an experiment changed nothing: 230.9 vs 229.9 us.)
+__global__ void __launch_bounds__(256) pad_image_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int pt, int pl, int hp, int wp) {
+	size_t total = (size_t)planes * hp * wp;
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		int x = (int)(e % wp) - pl; size_t t = e / wp;
+		int y = (int)(t % hp) - pt; size_t pc = t / hp;
+		dst[e] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? src[(pc * h + y) * w + x] : 0.f;
+	}
+}
+__global__ void __launch_bounds__(256) padded_tables_kernel(int2* taps, int2* pix, int c_n, int k, int hp, int wp, int ho, int wo) {
+	int e = blockIdx.x * blockDim.x + threadIdx.x;
+	int kk = k * k;
+	if (e < c_n * kk) { int c = e / kk, p = (e % kk) / k, q = e % k; taps[e] = make_int2(c * hp * wp + p * wp + q, 0); }
+	if (e < ho * wo) { int i = e / wo, j = e - i * wo; pix[e] = make_int2(i * wp + j, 0); }
+}
+struct PaddedTables { ConvGeom g; int2* taps; int2* pix; };
+static PaddedTables g_padded[64];
+static int g_num_padded = 0;
+
+static bla_status get_padded_tables(hipStream_t s, const ConvGeom& g, const int2** taps, const int2** pix) {
+	for (int i = 0; i < g_num_padded; i++) {
+		const ConvGeom& t = g_padded[i].g;
+		if (t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c) { *taps = g_padded[i].taps; *pix = g_padded[i].pix; return BLA_OK; }
+	}
+	BLA_REQUIRE(g_num_padded < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	int nt = g.c * g.k * g.k, np = g.ho * g.wo;
+	int2 *t, *q;
+	BLA_HIP(hipMalloc((void**)&t, (size_t)nt * sizeof(int2)));
+	BLA_HIP(hipMalloc((void**)&q, (size_t)np * sizeof(int2)));
+	int n = nt > np ? nt : np;
+	hipLaunchKernelGGL(padded_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, q, g.c, g.k, g.h + g.k - 1, g.w + g.k - 1, g.ho, g.wo);
+	BLA_HIP(hipGetLastError());
+	g_padded[g_num_padded++] = PaddedTables{g, t, q};
+	*taps = t; *pix = q;
+	return BLA_OK;
+}
+
+// A batch large enough to fill the chip with 128x128 tiles goes to the LDS-tiled gather kernel (bla_gemm.hip: same pipeline as the
+// dense GEMM, the B slab fetched by 4-byte direct-to-LDS loads from computed addresses); small batches and odd shapes stay on the
+// 32x32 wave-split-K gather kernel above.
+static bool use_tiled_gather(const ConvArgs& a, int batch, int mode) {
+	const long cols = mode == 1 ? (long)a.N * batch : (long)a.N;
+	const long kk = mode == 1 ? (long)a.K : (long)a.K * batch;
+	const long tiles = ((a.M + 127) / 128) * ((cols + 127) / 128);
+	const bool aligned = a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0;
+	if (!aligned || a.M < 64) return false;
+	if (mode == 1) return a.K % 16 == 0 && tiles >= 128;
+	return a.K % 16 == 0 && kk >= 16384 && tiles * batch >= 128;   // a.K = output pixels per image here
+}
+
 template <int MODE>
 static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, size_t img_stride = 0, size_t out_stride = 0, size_t a_stride = 0) {
 	a.batch = batch; a.img_stride = img_stride; a.out_stride = out_stride; a.a_stride = a_stride;
+	if (use_tiled_gather(a, batch, MODE == CONV_FWD ? 1 : 2)) {
+		const int2* ptab;
+		bla_status st = get_pixel_table(s, a.g, &ptab);
+		if (st) return st;
+		if (MODE == CONV_FWD && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w) {
+			// stride 1: pad once, then the B slab is fetched with the same 16-byte DMA as a dense operand
+			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
+			void* ws;
+			st = ensure_workspace((size_t)planes * hp * wp * sizeof(float) + 64, &ws);
+			if (st) return st;
+			const int2 *taps, *pix;
+			st = get_padded_tables(s, a.g, &taps, &pix);
+			if (st) return st;
+			hipLaunchKernelGGL(pad_image_kernel, dim3(grid_for((size_t)planes * hp * wp)), dim3(256), 0, s, a.img, (float*)ws, planes, a.g.h, a.g.w, a.g.pt, a.g.pl, hp, wp);
+			BLA_HIP(hipGetLastError());
+			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, (const float*)ws, taps, pix, hp, wp, a.N, a.g.c * hp * wp);
+		}
+		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
+			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
+		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
+		return gather_gemm(s, 2, batch, a.M, a.N, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, ptab, a.tab, a.g.h, a.g.w, a.K, (int)img_stride);
+	}
 	a.tiles_n = (a.N + 31) / 32;
 	int tiles = ((a.M + 31) / 32) * a.tiles_n;
 	// long contractions over few tiles are latency-bound: cut K over workgroups until ~3 of them sit on every CU,

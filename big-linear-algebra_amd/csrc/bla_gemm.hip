@@ -45,6 +45,15 @@ struct GemmArgs {
 	unsigned* counters;            // wsk kernels with splits > 1: one arrival counter per output tile (zero between launches)
 	float* row_sum_a;              // fused bias gradient: row_sum_a[r] = sum_k op(A)[r][k]   (wsk kernels, A K-contiguous)
 	const float* softmax_y; float softmax_scale; float* softmax_grad;   // fused column softmax + (p - y)*scale (wsk kernels, M <= 32)
+	// implicit-GEMM convolution over a batch of images (gather variants of the direct-to-LDS kernel only): the B operand is
+	// never stored, element (k, n) is img[g_off(k) + g_off(n)] when (y(k) + y(n), x(k) + x(n)) lies inside the H x W image, else 0.
+	//   mode 1 (forward / data gradient): n = (image, output pixel), k = tap (c, p, q);  C is written as [image][M][HWo]
+	//   mode 2 (weight gradient):         n = tap,                   k = (image, output pixel);  A = del_y [image][M][HWo]
+	//   mode 3 (forward, stride 1, zero-PADDED image copy): as mode 1 without bounds checks, and four consecutive output pixels of a
+	//           row are four consecutive floats of the padded image: 16-byte DMA exactly like a dense row-contiguous operand
+	const float* g_img; const float* g_zero;
+	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
+	int g_mode, g_H, g_W, g_HWo, g_img_stride;
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
@@ -263,8 +272,9 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
+	static_assert(GATHER == 0 || (AKC && !BKC && NBUF == 2 && !PERSIST && BN == 128 && BK == 16 && WM * WN == 4), "gather variant: A K-contiguous, B gathered as a [16][128] image");
 	constexpr int NW = WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
@@ -294,7 +304,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 
 	// Per-lane source pointers of this wave's DMA instructions for slab 0 of a tile (advance by BK per slab).
 	constexpr int A_NI = (AKC ? AI::NINST : BK * BM / 256) / NW;   // wave-instructions per wave per slab
-	constexpr int B_NI = (BKC ? BI::NINST : BK * BN / 256) / NW;
+	constexpr int B_NI = (GATHER == 1 || GATHER == 2) ? BK * BN / 64 / NW : (BKC ? BI::NINST : BK * BN / 256) / NW;   // checked gather: dword DMA, 64 columns of one k-row per instruction
 	static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for the wave count");
 	const float* ga[A_NI];
 	const float* gb[B_NI];
@@ -315,7 +325,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 				ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(tm0 + c, p.M - 4);
 			}
 		}
-		if (BKC) {
+		if (GATHER) {
+			// nothing per tile for B: the gather addresses are rebuilt per slab from the lane / scalar table entries below
+		} else if (BKC) {
 #pragma unroll
 			for (int i = 0; i < B_NI; i++) {
 				int inst = wave * B_NI + i;
@@ -332,6 +344,38 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		}
 	};
 	open_tile(m0, n0);
+	// gather state: this lane's two columns (n0 + lane, n0 + 64 + lane) -> {element offset, y | x << 16}, and the scalar cursor
+	int g_loff[2] = {0, 0}, g_lyx[2] = {0, 0};
+	bool g_lval[2] = {false, false};
+	int g_k = k_begin;            // k of the next slab to fetch
+	int g_img = 0, g_r = 0;       // mode 2: image and pixel of g_k
+	int g3_base = 0;              // mode 3: padded-image offset of this lane's four columns
+	if (GATHER == 3) {
+		int n = min(n0 + (lane & 31) * 4, p.N - 4);
+		int b = n / p.g_HWo, r = n - b * p.g_HWo;
+		g3_base = p.g_ntab[r].x + b * p.g_img_stride;
+	}
+	if (GATHER == 1 || GATHER == 2) {
+#pragma unroll
+		for (int hf = 0; hf < 2; hf++) {
+			int n = n0 + hf * 64 + lane;
+			g_lval[hf] = n < p.N;
+			n = min(n, p.N - 1);
+			if (GATHER == 1) {
+				int b = n / p.g_HWo, r = n - b * p.g_HWo;
+				int2 t = p.g_ntab[r];
+				g_loff[hf] = t.x + b * p.g_img_stride; g_lyx[hf] = t.y;
+			} else {
+				int2 t = p.g_ntab[n];
+				g_loff[hf] = t.x; g_lyx[hf] = t.y;
+			}
+		}
+		if (GATHER == 2) {
+			g_img = k_begin / p.g_HWo; g_r = k_begin - g_img * p.g_HWo;
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) ga[i] += (ptrdiff_t)g_img * p.M * p.g_HWo + (g_r - k_begin);   // A = del_y [image][M][HWo]: row stride lda = HWo
+		}
+	}
 
 	typedef __attribute__((address_space(3))) void* lds_ptr_t;
 	typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -342,10 +386,40 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 			ga[i] += a_step;
 		}
+		if (GATHER == 3) {
 #pragma unroll
-		for (int i = 0; i < B_NI; i++) {
-			__builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
-			gb[i] += b_step;
+			for (int i = 0; i < B_NI; i++) {
+				const int idx = wave * B_NI + i, kr = idx * 2 + (lane >> 5);
+				const float* src = p.g_img + (g3_base + p.g_ktab[g_k + kr].x);
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + idx * 256), 16, 0, 0);
+			}
+			g_k += BK;
+		} else if (GATHER) {
+			const int simg = GATHER == 2 ? g_img * p.g_img_stride : 0;
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) {
+				const int idx = wave * B_NI + i, krow = idx >> 1, hf = idx & 1;            // wave-uniform
+				const int2 ts = p.g_ktab[GATHER == 1 ? g_k + krow : g_r + krow];            // scalar load
+				const int yy = (short)(g_lyx[hf] & 0xffff) + (short)(ts.y & 0xffff), xx = (g_lyx[hf] >> 16) + (ts.y >> 16);
+				const bool ok = g_lval[hf] && (unsigned)yy < (unsigned)p.g_H && (unsigned)xx < (unsigned)p.g_W;
+				const float* src = ok ? p.g_img + (g_loff[hf] + ts.x + simg) : p.g_zero;
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + krow * BN + hf * 64), 4, 0, 0);
+			}
+			g_k += BK;
+			if (GATHER == 2) {
+				g_r += BK;
+				if (g_r >= p.g_HWo) {   // next image (HWo % 16 == 0: a slab never straddles two)
+					g_r = 0; g_img++;
+#pragma unroll
+					for (int i = 0; i < A_NI; i++) ga[i] += (size_t)(p.M - 1) * p.g_HWo;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) {
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
+				gb[i] += b_step;
+			}
 		}
 	};
 
@@ -426,6 +500,23 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	};
 
 	auto store_tile = [&]() {
+		if (GATHER == 1 || GATHER == 3) {   // C is [image][M][HWo]: column n = (image, pixel)
+#pragma unroll
+			for (int in = 0; in < TN; in++) {
+				int col = n0 + wn0 + in * 32 + l31;
+				if (col >= p.N) continue;
+				int b = col / p.g_HWo, r = col - b * p.g_HWo;
+				float* cbase = p.C + (size_t)b * p.M * p.g_HWo + r;
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int q = 0; q < 16; q++) {
+						int row = m0 + wm0 + im * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+						if (row < p.M) cbase[(size_t)row * p.g_HWo] = acc[im][in][q];
+					}
+			}
+			return;
+		}
 #pragma unroll
 		for (int im = 0; im < TM; im++)
 #pragma unroll
@@ -938,6 +1029,54 @@ static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, b
 	BLA_WV(false, true);
 #undef BLA_WV
 #undef BLA_W
+}
+
+bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride) {
+	BLA_REQUIRE(mode >= 1 && mode <= 3, BLA_ERR_INVALID, "gather mode %d", mode);
+	BLA_REQUIRE(mode != 3 || (N % 4 == 0 && HWo % 4 == 0 && N >= 4), BLA_ERR_INVALID, "mode 3 needs pixel counts that are multiples of 4");
+	BLA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && (mode == 1 || HWo % 16 == 0), BLA_ERR_INVALID,
+	            "gathered product needs K %% 16 == 0 and a 16-byte aligned A (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
+	BLA_REQUIRE((long)batch * img_stride < (1L << 31) && (long)N < (1L << 31), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
+	GemmArgs a = {};
+	a.A = A; a.B = nullptr; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = 0; a.ldc = ldc;
+	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
+	a.g_img = img; a.g_zero = zero_word(); a.g_ktab = ktab; a.g_ntab = ntab; a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
+	a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	int splits = 1;
+	if (mode == 2) {   // contraction over (image, pixel): whole images per split, ~2 workgroups per CU
+		long tiles = (long)a.tiles_m * a.tiles_n;
+		long want = (2L * cus + tiles - 1) / tiles;
+		splits = (int)(want < batch ? want : batch);
+		if (splits < 1) splits = 1;
+		int ips = (batch + splits - 1) / splits;   // images per split
+		splits = (batch + ips - 1) / ips;
+		a.k_per_split = ips * HWo;
+	} else {
+		a.k_per_split = K;
+	}
+	a.splits = splits; a.slab = nullptr;
+	if (splits > 1) {
+		void* ws;
+		bla_status st = ensure_workspace((size_t)splits * M * N * sizeof(float), &ws);
+		if (st) return st;
+		a.slab = (float*)ws;
+	}
+	dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits), block(256);
+	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
+	if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
+	else if (mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3>), grid, block, lds_bytes, s, a);
+	else hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 2>), grid, block, lds_bytes, s, a);
+	BLA_HIP(hipGetLastError());
+	if (splits > 1) {
+		size_t total = (size_t)M * N;
+		unsigned blocks = (unsigned)((total + 255) / 256);
+		if (blocks > 2048u) blocks = 2048u;
+		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+		BLA_HIP(hipGetLastError());
+	}
+	return BLA_OK;
 }
 
 }  // namespace bla

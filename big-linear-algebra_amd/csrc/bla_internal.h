@@ -28,6 +28,14 @@ bla_status ensure_workspace(size_t bytes, void** out);
 // out[i] = sum_{j<len} m[i*stride + j], i < count (bla_elementwise.hip)
 bla_status window_sum(void* stream, const float* m, int count, int len, int stride, float* out);
 inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : ctx().stream; }
+// a device word that is always 0.0f (source address of the zero padding in gathered operands)
+inline const float* zero_word() { return reinterpret_cast<const float*>(ctx().tile_counters + 16384); }
+// Implicit-GEMM convolution over a batch of images on the direct-to-LDS 128x128x16 kernel, B operand gathered (bla_gemm.hip):
+//   mode 1: C [batch][M][HWo] = A [M][K] . G,   n = (image, output pixel), k = tap;   ktab = taps, ntab = pixels
+//   mode 2: C [M][N]          = sum_images A_b [M][HWo] . G_b^T,   n = tap, k = (image, pixel);   ktab = pixels, ntab = taps
+// tables: {element offset, y | x << 16}.  Needs K % 16 == 0 (mode 2: HWo % 16 == 0), A 16-byte aligned with lda % 4 == 0.
+bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride);
 
 #define BLA_HIP(call)                                               \
 	do {                                                            \

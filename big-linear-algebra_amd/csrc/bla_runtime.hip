@@ -86,8 +86,8 @@ bla_status bla_init(int device) {
 		g_ctx = Context();
 	}
 	BLA_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-	BLA_HIP(hipMalloc((void**)&g_ctx.tile_counters, 16384 * sizeof(unsigned)));
-	BLA_HIP(hipMemset(g_ctx.tile_counters, 0, 16384 * sizeof(unsigned)));
+	BLA_HIP(hipMalloc((void**)&g_ctx.tile_counters, (16384 + 64) * sizeof(unsigned)));   // + 64 words that stay zero (zero_word())
+	BLA_HIP(hipMemset(g_ctx.tile_counters, 0, (16384 + 64) * sizeof(unsigned)));
 	g_ctx.device = device;
 	g_ctx.num_cus = prop.multiProcessorCount;
 	strncpy(g_ctx.arch, prop.gcnArchName, sizeof(g_ctx.arch) - 1);
