@@ -451,6 +451,21 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
+		if (MODE == CONV_WGRAD && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w && a.N % 4 == 0) {
+			// stride 1: transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
+			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
+			const size_t slab_bytes = (size_t)gather_gemm_splits(4, batch, a.N, a.M) * a.M * a.N * sizeof(float);
+			void* ws;
+			st = ensure_workspace(slab_bytes + (size_t)planes * hp * wp * sizeof(float) + 64, &ws);   // [slabs][padded copy]
+			if (st) return st;
+			float* padded = (float*)((char*)ws + slab_bytes);
+			const int2 *taps, *pix;
+			st = get_padded_tables(s, a.g, &taps, &pix);
+			if (st) return st;
+			hipLaunchKernelGGL(pad_image_kernel, dim3(grid_for((size_t)planes * hp * wp)), dim3(256), 0, s, a.img, padded, planes, a.g.h, a.g.w, a.g.pt, a.g.pl, hp, wp);
+			BLA_HIP(hipGetLastError());
+			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, hp, wp, a.K, a.g.c * hp * wp);
+		}
 		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
 		return gather_gemm(s, 2, batch, a.M, a.N, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, ptab, a.tab, a.g.h, a.g.w, a.K, (int)img_stride);
 	}

@@ -51,6 +51,9 @@ struct GemmArgs {
 	//   mode 2 (weight gradient):         n = tap,                   k = (image, output pixel);  A = del_y [image][M][HWo]
 	//   mode 3 (forward, stride 1, zero-PADDED image copy): as mode 1 without bounds checks, and four consecutive output pixels of a
 	//           row are four consecutive floats of the padded image: 16-byte DMA exactly like a dense row-contiguous operand
+	//   mode 4 (weight gradient, stride 1, padded copy), transposed: C'[tap][f] = sum_(image,pixel) P[tap][(image,pixel)] . del_y[f][(image,pixel)]:
+	//           both operands K-contiguous (the gathered one in 16-byte chunks of four pixels), B = del_y [image][N][HWo], the tile is
+	//           stored transposed (dkern [f][tap], or slab [split][f][tap])
 	const float* g_img; const float* g_zero;
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
@@ -274,7 +277,8 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
-	static_assert(GATHER == 0 || (AKC && !BKC && NBUF == 2 && !PERSIST && BN == 128 && BK == 16 && WM * WN == 4), "gather variant: A K-contiguous, B gathered as a [16][128] image");
+	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && BN == 128 && BK == 16 && WM * WN == 4),
+	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image, mode 4 gathers A and takes a K-contiguous B");
 	constexpr int NW = WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 				ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(tm0 + c, p.M - 4);
 			}
 		}
-		if (GATHER) {
+		if (GATHER >= 1 && GATHER <= 3) {
 			// nothing per tile for B: the gather addresses are rebuilt per slab from the lane / scalar table entries below
 		} else if (BKC) {
 #pragma unroll
@@ -349,6 +353,19 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	bool g_lval[2] = {false, false};
 	int g_k = k_begin;            // k of the next slab to fetch
 	int g_img = 0, g_r = 0;       // mode 2: image and pixel of g_k
+	int g4_tap[A_NI], g4_chunk[A_NI];   // mode 4: padded offset of this lane's tap row, and its (swizzled) pixel chunk, per A instruction
+	if (GATHER == 4) {
+#pragma unroll
+		for (int i = 0; i < A_NI; i++) {
+			int inst = wave * A_NI + i;
+			int r = inst * AI::RPI + lane / AI::CPR, pos = lane % AI::CPR;
+			g4_tap[i] = p.g_ntab[min(m0 + r, p.M - 1)].x;
+			g4_chunk[i] = AI::swz(r, pos) * 4;
+		}
+		g_img = k_begin / p.g_HWo; g_r = k_begin - g_img * p.g_HWo;
+#pragma unroll
+		for (int i = 0; i < B_NI; i++) gb[i] += (ptrdiff_t)g_img * p.N * p.g_HWo + (g_r - k_begin);   // B = del_y [image][N][HWo], ldb = HWo
+	}
 	int g3_base = 0;              // mode 3: padded-image offset of this lane's four columns
 	if (GATHER == 3) {
 		int n = min(n0 + (lane & 31) * 4, p.N - 4);
@@ -381,6 +398,26 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 	auto dma = [&](int buf) {
 		float* base = lds + buf * (A_SZ + B_SZ);
+		if (GATHER == 4) {
+			const float* ib = p.g_img + g_img * p.g_img_stride;
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) {
+				const float* src = ib + (g4_tap[i] + p.g_ktab[g_r + g4_chunk[i]].x);
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+			}
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) {
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
+				gb[i] += b_step;
+			}
+			g_r += BK;
+			if (g_r >= p.g_HWo) {
+				g_r = 0; g_img++;
+#pragma unroll
+				for (int i = 0; i < B_NI; i++) gb[i] += (size_t)(p.N - 1) * p.g_HWo;
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < A_NI; i++) {
 			__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
@@ -500,6 +537,25 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	};
 
 	auto store_tile = [&]() {
+		if (GATHER == 4) {   // transposed: tile element (row = tap, col = f) -> out[f][tap]; a lane's registers q&3 are 4 consecutive taps
+			float* dst = p.splits > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.N : p.C;
+			const int ld = p.splits > 1 ? p.M : p.ldc;
+#pragma unroll
+			for (int in = 0; in < TN; in++) {
+				int col = n0 + wn0 + in * 32 + l31;
+				if (col >= p.N) continue;
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int qq = 0; qq < 4; qq++) {
+						int row = m0 + wm0 + im * 32 + 8 * qq + 4 * h;
+						if (row + 3 < p.M)
+							*reinterpret_cast<float4*>(dst + (size_t)col * ld + row) =
+								make_float4(acc[im][in][4 * qq], acc[im][in][4 * qq + 1], acc[im][in][4 * qq + 2], acc[im][in][4 * qq + 3]);
+					}
+			}
+			return;
+		}
 		if (GATHER == 1 || GATHER == 3) {   // C is [image][M][HWo]: column n = (image, pixel)
 #pragma unroll
 			for (int in = 0; in < TN; in++) {
@@ -1031,31 +1087,34 @@ static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, b
 #undef BLA_W
 }
 
+int gather_gemm_splits(int mode, int batch, int M, int N) {
+	if (mode != 2 && mode != 4) return 1;
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+	long want = (2L * cus + tiles - 1) / tiles;   // contraction over (image, pixel): whole images per split, ~2 workgroups per CU
+	int splits = (int)(want < batch ? want : batch);
+	if (splits < 1) splits = 1;
+	int ips = (batch + splits - 1) / splits;      // images per split
+	return (batch + ips - 1) / ips;
+}
+
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
                        const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride) {
-	BLA_REQUIRE(mode >= 1 && mode <= 3, BLA_ERR_INVALID, "gather mode %d", mode);
+	BLA_REQUIRE(mode >= 1 && mode <= 4, BLA_ERR_INVALID, "gather mode %d", mode);
 	BLA_REQUIRE(mode != 3 || (N % 4 == 0 && HWo % 4 == 0 && N >= 4), BLA_ERR_INVALID, "mode 3 needs pixel counts that are multiples of 4");
-	BLA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && (mode == 1 || HWo % 16 == 0), BLA_ERR_INVALID,
-	            "gathered product needs K %% 16 == 0 and a 16-byte aligned A (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
+	BLA_REQUIRE(mode != 4 || M % 4 == 0, BLA_ERR_INVALID, "mode 4 needs a tap count that is a multiple of 4");
+	BLA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && ((mode != 2 && mode != 4) || HWo % 16 == 0), BLA_ERR_INVALID,
+	            "gathered product needs K %% 16 == 0 and a 16-byte aligned dense operand (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
 	BLA_REQUIRE((long)batch * img_stride < (1L << 31) && (long)N < (1L << 31), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
 	GemmArgs a = {};
-	a.A = A; a.B = nullptr; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = 0; a.ldc = ldc;
+	a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+	if (mode == 4) { a.A = nullptr; a.lda = 0; a.B = A; a.ldb = lda; }      // the dense operand (del_y) is the K-contiguous B
+	else { a.A = A; a.lda = lda; a.B = nullptr; a.ldb = 0; }
 	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
 	a.g_img = img; a.g_zero = zero_word(); a.g_ktab = ktab; a.g_ntab = ntab; a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
 	a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
-	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
-	int splits = 1;
-	if (mode == 2) {   // contraction over (image, pixel): whole images per split, ~2 workgroups per CU
-		long tiles = (long)a.tiles_m * a.tiles_n;
-		long want = (2L * cus + tiles - 1) / tiles;
-		splits = (int)(want < batch ? want : batch);
-		if (splits < 1) splits = 1;
-		int ips = (batch + splits - 1) / splits;   // images per split
-		splits = (batch + ips - 1) / ips;
-		a.k_per_split = ips * HWo;
-	} else {
-		a.k_per_split = K;
-	}
+	const int splits = gather_gemm_splits(mode, batch, M, N);
+	a.k_per_split = (mode == 2 || mode == 4) ? (batch + splits - 1) / splits * HWo : K;
 	a.splits = splits; a.slab = nullptr;
 	if (splits > 1) {
 		void* ws;
@@ -1066,14 +1125,17 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits), block(256);
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
 	if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
+	else if (mode == 2) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 2>), grid, block, lds_bytes, s, a);
 	else if (mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3>), grid, block, lds_bytes, s, a);
-	else hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 2>), grid, block, lds_bytes, s, a);
+	else hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4>), grid, block, lds_bytes, s, a);
 	BLA_HIP(hipGetLastError());
 	if (splits > 1) {
+		GemmArgs r = a;
+		if (mode == 4) { r.M = N; r.N = M; }   // the slabs hold the transposed tile: [split][N][M] -> C [N][M]
 		size_t total = (size_t)M * N;
 		unsigned blocks = (unsigned)((total + 255) / 256);
 		if (blocks > 2048u) blocks = 2048u;
-		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, r);
 		BLA_HIP(hipGetLastError());
 	}
 	return BLA_OK;
