@@ -126,8 +126,10 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
                     ex.close()
                 ex = None
         if ex is not None:
-            exchange_name = ("one-kernel SUM all-reduce + SGD update: every rank reads its peers' 235146-float gradient buckets "
-                             "directly over xGMI (IPC-mapped fine-grained memory, flag-synchronised), whole step = one hipGraph launch")
+            algo = os.environ.get("BLA_DP_ALGO") or ("twoshot" if world >= 4 else "oneshot")
+            exchange_name = ("one-kernel SUM all-reduce + SGD update (" + algo + "): every rank reads its peers' 235146-float gradient buckets "
+                             + ("slice-wise (reduce-scatter, then the reduced slices) " if algo == "twoshot" else "")
+                             + "directly over xGMI (IPC-mapped fine-grained memory, flag-synchronised), whole step = one hipGraph launch")
 
             def step():
                 nn.dp_step(ex, stream=stream)

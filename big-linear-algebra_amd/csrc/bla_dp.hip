@@ -14,11 +14,20 @@
 //   reader p, epoch e : spin until flag[p][r] >= e for every r (system-scope acquire), then read bucket_r[e&1]
 // Rank r overwrites bucket[(e+1)&1] only after its own epoch-e exchange finished, which needed every peer's
 // epoch-e flag, which each peer pushed after completing its epoch-(e-1) exchange -- the last reader of that bucket.
-// So no second barrier is needed.  Shared memory is fine-grained (uncached in L2, coherent at system scope) and
+// So no second barrier is needed.
+//
+// From four ranks up the exchange runs in two shots inside the same kernel (each link then carries 2/R of a bucket instead of a
+// whole one -- 4x less at R = 8): rank r sums slice r of every peer's bucket (rank order) into its own `reduced` buffer, the
+// workgroup that finishes that phase last pushes a second flag, and every rank then pulls the R-1 reduced slices of its peers.
+// All ranks end up with the owner's sums, so the result is bit-identical to the one-shot form.  The second phase waits on
+// workgroups of the same launch on other GPUs, so that launch is kept small enough (128 workgroups) to be fully resident.
+//
+// Shared memory is fine-grained (uncached in L2, coherent at system scope) and
 // exported / opened with hipIpc*MemHandle, one process per GPU.  A wait that exceeds the time-out raises the
 // status word instead of spinning forever.
 #include "bla_internal.h"
 #include <cstring>
+#include <cstdlib>
 
 using namespace bla;
 
@@ -37,7 +46,112 @@ struct DpKernelArgs {
 	unsigned n4;                          // float4 groups, the last one possibly partial
 	unsigned count;                       // floats in out / target (the source buckets are padded allocations)
 	int world, rank;
+	// two-shot form
+	const float* red[kMaxWorld];          // reduced slice of rank r for this parity (own: local pointer, written in phase A)
+	float* red_self;
+	unsigned* peer_flags_b[kMaxWorld];    // second flag array ("my reduced slice is ready") in rank p's memory
+	unsigned* flags_b;
+	unsigned per4;                        // float4 groups per slice: slice r = [r * per4, min((r + 1) * per4, n4))
 };
+
+__device__ __forceinline__ float4 load16_nt(const float* base, size_t i4) {
+	typedef float vf4 __attribute__((ext_vector_type(4)));
+	vf4 x = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(base) + i4);
+	return make_float4(x.x, x.y, x.z, x.w);
+}
+
+// out / target hold `count` floats (possibly a foreign, unpadded buffer): the last float4 group may be partial
+__device__ __forceinline__ void deliver(const DpKernelArgs& a, unsigned i, float4 s) {
+	if (4 * i + 4 <= a.count) {
+		if (a.out) reinterpret_cast<float4*>(a.out)[i] = s;
+		if (a.target) {
+			float4 t = reinterpret_cast<float4*>(a.target)[i];
+			t.x += a.alpha * s.x; t.y += a.alpha * s.y; t.z += a.alpha * s.z; t.w += a.alpha * s.w;
+			reinterpret_cast<float4*>(a.target)[i] = t;
+		}
+	} else {
+		const float sv[4] = {s.x, s.y, s.z, s.w};
+		for (unsigned j = 0; 4 * i + j < a.count; j++) {
+			if (a.out) a.out[4 * i + j] = sv[j];
+			if (a.target) a.target[4 * i + j] += a.alpha * sv[j];
+		}
+	}
+}
+
+// wait until flags[r] has reached `epoch` for every r < world (threads r < world poll); returns false on time-out
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int world, unsigned epoch, int* s_fail) {
+	if ((int)threadIdx.x < world) {
+		const long long t0 = wall_clock64();
+		while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+			__builtin_amdgcn_s_sleep(4);
+			if (wall_clock64() - t0 > kTimeoutTicks) { *s_fail = 1; break; }
+		}
+	}
+	__syncthreads();
+	return *s_fail == 0;
+}
+
+__global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs a) {
+	__shared__ int s_fail;
+	__shared__ int s_last;
+	const unsigned epoch = a.state[0] + 1;
+	if (threadIdx.x == 0) { s_fail = 0; s_last = 0; }
+	__syncthreads();
+	if (blockIdx.x == 0 && (int)threadIdx.x < a.world) {
+		__threadfence_system();
+		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	bool ok = wait_flags(a.flags, a.world, epoch, &s_fail);
+	// phase A: my slice of every bucket, summed in rank order -> reduced buffer (for the peers) and my own out / target
+	const unsigned lo = a.rank * a.per4, hi = min(lo + a.per4, a.n4);
+	if (ok) {
+		for (unsigned i = lo + blockIdx.x * 256 + threadIdx.x; i < hi; i += gridDim.x * 256) {
+			float4 v[kMaxWorld];
+#pragma unroll
+			for (int r = 0; r < kMaxWorld; r++)
+				if (r < a.world) v[r] = load16_nt(a.src[r], i);
+			float4 s = v[0];
+#pragma unroll
+			for (int r = 1; r < kMaxWorld; r++)
+				if (r < a.world) { s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w; }
+			reinterpret_cast<float4*>(a.red_self)[i - lo] = s;
+			deliver(a, i, s);
+		}
+	}
+	// the workgroup that leaves phase A last publishes "my reduced slice is ready" to every peer
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__threadfence_system();
+		s_last = atomicAdd(a.state + 3, 1u) == gridDim.x - 1;
+	}
+	__syncthreads();
+	if (s_last) {
+		if (threadIdx.x == 0) a.state[3] = 0;
+		if ((int)threadIdx.x < a.world) {
+			__threadfence_system();
+			__hip_atomic_store(a.peer_flags_b[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+	// phase B: the peers' reduced slices
+	ok = wait_flags(a.flags_b, a.world, epoch, &s_fail) && ok;
+	if (ok) {
+		const unsigned rest = a.n4 - (hi - lo);   // groups owned by the peers
+		for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < rest; j += gridDim.x * 256) {
+			const unsigned i = j < lo ? j : j + (hi - lo);      // skip my own slice
+			const unsigned owner = i / a.per4;
+			deliver(a, i, load16_nt(a.red[owner], i - owner * a.per4));
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_fail) atomicOr(a.state + 2, 1u);
+		__threadfence();
+		if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {
+			a.state[1] = 0;
+			__hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
 
 __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 	__shared__ int s_fail;
@@ -105,8 +219,10 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 struct bla_dp {
 	int rank, world;
 	size_t count, padded;        // floats; padded to a multiple of 1024
-	char* base; size_t bytes;    // own fine-grained allocation: [bucket 0][bucket 1][flags]
-	size_t flags_off;
+	char* base; size_t bytes;    // own fine-grained allocation: [bucket 0][bucket 1][reduced 0][reduced 1][flags A][flags B]
+	size_t red_off, flags_off;
+	unsigned per4;               // float4 groups per slice of the two-shot form
+	bool twoshot;
 	unsigned* state;             // local (ordinary device memory)
 	void* peer[kMaxWorld];       // opened peer allocations (own slot = base)
 	bool connected;
@@ -122,8 +238,14 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	bla_dp* dp = new bla_dp();
 	dp->rank = rank; dp->world = world; dp->count = count;
 	dp->padded = (count + 1023) / 1024 * 1024;
-	dp->flags_off = 2 * dp->padded * sizeof(float);
+	const unsigned n4 = (unsigned)((count + 3) / 4);
+	dp->per4 = (n4 + world - 1) / world;
+	dp->red_off = 2 * dp->padded * sizeof(float);
+	dp->flags_off = dp->red_off + 2 * (size_t)dp->per4 * 16;
 	dp->bytes = dp->flags_off + 4096;
+	// two shots pay a second flag round to move 2/R of a bucket per link instead of a whole one: worth it from four ranks up
+	const char* algo = getenv("BLA_DP_ALGO");
+	dp->twoshot = algo ? strcmp(algo, "twoshot") == 0 : world >= 4;
 	void* p = nullptr;
 	hipError_t e = hipExtMallocWithFlags(&p, dp->bytes, hipDeviceMallocFinegrained);
 	if (e != hipSuccess) { delete dp; return hip_fail(e, "hipExtMallocWithFlags(fine-grained exchange buffer)"); }
@@ -206,11 +328,27 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 	a.out = d_out; a.target = d_target; a.alpha = alpha;
 	a.n4 = (unsigned)((dp->count + 3) / 4); a.count = (unsigned)dp->count;
 	a.world = dp->world; a.rank = dp->rank;
-	unsigned blocks = (a.n4 + 255) / 256;
-	const unsigned cap = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
-	if (blocks > cap) blocks = cap;
-	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(dp_allreduce_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);
+	const unsigned cus = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+	if (dp->twoshot && dp->world > 1) {
+		for (int r = 0; r < dp->world; r++) {
+			a.red[r] = (const float*)((char*)dp->peer[r] + dp->red_off + (size_t)(parity & 1) * dp->per4 * 16);
+			a.peer_flags_b[r] = (unsigned*)((char*)dp->peer[r] + dp->flags_off + 2048);
+		}
+		a.red_self = (float*)(dp->base + dp->red_off + (size_t)(parity & 1) * dp->per4 * 16);
+		a.flags_b = (unsigned*)(dp->base + dp->flags_off + 2048);
+		a.per4 = dp->per4;
+		// the second phase waits for workgroups of this same launch (here and on the peers): keep the grid fully resident
+		unsigned blocks = (a.n4 - a.per4 + 255) / 256;
+		const unsigned cap = cus / 2 < 128 ? (cus / 2 ? cus / 2 : 1) : 128;
+		if (blocks > cap) blocks = cap;
+		if (blocks < 1) blocks = 1;
+		hipLaunchKernelGGL(dp_allreduce_twoshot_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);
+	} else {
+		unsigned blocks = (a.n4 + 255) / 256;
+		if (blocks > cus) blocks = cus;
+		if (blocks < 1) blocks = 1;
+		hipLaunchKernelGGL(dp_allreduce_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);
+	}
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }

@@ -22,8 +22,8 @@ def dev():
     return bla
 
 
-def run_ranks(world, tmp, steps, per):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def run_ranks(world, tmp, steps, per, algo):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLA_DP_ALGO=algo)
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(tmp), str(steps), str(per)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs, failed = [], False
@@ -38,10 +38,12 @@ def run_ranks(world, tmp, steps, per):
     return [np.load(os.path.join(tmp, f"result{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_exchange_between_processes(dev, world, tmp_path):
+@pytest.mark.parametrize("world,algo", [(2, "oneshot"), (2, "twoshot"), (4, "oneshot"), (4, "twoshot"), (3, "twoshot")])
+def test_exchange_between_processes(dev, world, algo, tmp_path):
+    """algo: one kernel pulling whole peer buckets, or reduce-scatter + all-gather inside one kernel (the default from 4 ranks up);
+    both sum in rank order, so the expected bits are the same."""
     steps, per = 3, 64
-    res = run_ranks(world, str(tmp_path), steps, per)
+    res = run_ranks(world, str(tmp_path), steps, per, algo)
     count = 10007
     tgt = np.full(count, 1.0, np.float32)
     for rnd in range(3):
