@@ -110,21 +110,28 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
         import torch
         mode = os.environ.get("BLA_BENCH_EXCHANGE", "direct")   # direct = csrc/bla_dp.hip (peer reads over xGMI), rccl = library all-reduce
         if mode == "direct":
-            def gather(b):
-                out = [None] * world
-                dist.all_gather_object(out, b)
-                return out
+            def all_agree(flag):   # every rank must take the same path
+                t = torch.tensor([1 if flag else 0], device="cuda", dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
             try:
-                ex = mn.Exchange(rank, world, nn.count, gather)
-            except Exception as e:   # IPC mapping refused on this node: every rank must agree before falling back
-                print(f"[bench] rank {rank}: direct exchange unavailable ({e})", file=sys.stderr, flush=True)
+                ex = mn.Exchange(rank, world, nn.count)          # local: fine-grained buckets + flags
+            except Exception as e:
+                print(f"[bench] rank {rank}: exchange buffers unavailable ({e})", file=sys.stderr, flush=True)
                 ex = None
-            ok = torch.tensor([1 if ex is not None else 0], device="cuda", dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if ex is not None:
-                    ex.close()
-                ex = None
+            if all_agree(ex is not None):
+                handles = [None] * world
+                dist.all_gather_object(handles, ex.export())     # 64 bytes per rank, once
+                try:
+                    ex.connect(handles)                          # local: map the peers' buffers (IPC)
+                    mapped = True
+                except Exception as e:
+                    print(f"[bench] rank {rank}: peer mapping refused ({e})", file=sys.stderr, flush=True)
+                    mapped = False
+                if not all_agree(mapped):
+                    ex.close(); ex = None
+            elif ex is not None:
+                ex.close(); ex = None
         if ex is not None:
             algo = os.environ.get("BLA_DP_ALGO") or ("twoshot" if world >= 4 else "oneshot")
             exchange_name = ("one-kernel SUM all-reduce + SGD update (" + algo + "): every rank reads its peers' 235146-float gradient buckets "
@@ -133,7 +140,15 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
 
             def step():
                 nn.dp_step(ex, stream=stream)
-        else:
+            # two trial steps, then every rank reports whether a peer ever failed to show up (4 s time-out inside the kernel):
+            # a node whose peer mappings do not behave falls back to the library collective instead of failing the run
+            if os.environ.get("BLA_BENCH_NO_TRIAL") != "1":
+                step(); step()
+            if os.environ.get("BLA_BENCH_NO_TRIAL") != "1" and not all_agree(ex.status() == 0):
+                print(f"[bench] rank {rank}: direct exchange timed out, falling back to the RCCL all-reduce", file=sys.stderr, flush=True)
+                ex.close(); ex = None
+                nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+        if ex is None:
             exchange_name = "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"
             params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
             grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)

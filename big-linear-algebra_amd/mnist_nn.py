@@ -121,16 +121,23 @@ class Exchange:
     host-side channel (torch.distributed.all_gather_object, MPI, ...): it only carries the 64-byte IPC handles once."""
 
     def __init__(self, rank, world, count, all_gather_bytes=None):
+        """With `all_gather_bytes` the peers are connected here; without it (and world > 1) call export() / connect() yourself,
+        e.g. to let every rank agree on a fallback between the local steps."""
         self.L = native.lib()
         h = C.c_void_p()
         native.check(self.L.bla_dp_create(C.byref(h), rank, world, count))
         self.h, self.rank, self.world, self.count = h, rank, world, count
-        if world > 1:
-            buf = C.create_string_buffer(64)
-            native.check(self.L.bla_dp_export(self.h, buf))
-            handles = all_gather_bytes(buf.raw)
-            assert len(handles) == world and all(len(x) == 64 for x in handles)
-            native.check(self.L.bla_dp_connect(self.h, b"".join(handles)))
+        if world > 1 and all_gather_bytes is not None:
+            self.connect(all_gather_bytes(self.export()))
+
+    def export(self):
+        buf = C.create_string_buffer(64)
+        native.check(self.L.bla_dp_export(self.h, buf))
+        return buf.raw
+
+    def connect(self, handles):
+        assert len(handles) == self.world and all(len(x) == 64 for x in handles)
+        native.check(self.L.bla_dp_connect(self.h, b"".join(handles)))
 
     def bucket(self, parity):
         return self.L.bla_dp_bucket(self.h, parity)
