@@ -227,4 +227,43 @@ bla_status bla_event_elapsed_ms(void* a, void* b, float* ms) {
 	return BLA_OK;
 }
 
+struct BlaGraph { hipGraph_t graph; hipGraphExec_t exec; };
+
+bla_status bla_graph_begin(void* stream) {
+	bla_status st = require_ready();
+	if (st) return st;
+	hipStream_t s = pick_stream(stream);
+	BLA_HIP(hipStreamSynchronize(s));
+	BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+	return BLA_OK;
+}
+
+bla_status bla_graph_end(void* stream, void** graph) {
+	BLA_REQUIRE(graph, BLA_ERR_INVALID, "null argument");
+	hipStream_t s = pick_stream(stream);
+	hipGraph_t g = nullptr;
+	BLA_HIP(hipStreamEndCapture(s, &g));
+	hipGraphExec_t ex = nullptr;
+	hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+	if (e != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e, "hipGraphInstantiate"); }
+	BlaGraph* bg = new BlaGraph{g, ex};
+	*graph = bg;
+	return BLA_OK;
+}
+
+bla_status bla_graph_launch(void* graph, void* stream) {
+	BLA_REQUIRE(graph, BLA_ERR_INVALID, "null graph");
+	BLA_HIP(hipGraphLaunch(((BlaGraph*)graph)->exec, pick_stream(stream)));
+	return BLA_OK;
+}
+
+bla_status bla_graph_destroy(void* graph) {
+	if (!graph) return BLA_OK;
+	BlaGraph* bg = (BlaGraph*)graph;
+	(void)hipGraphExecDestroy(bg->exec);
+	(void)hipGraphDestroy(bg->graph);
+	delete bg;
+	return BLA_OK;
+}
+
 }  // extern "C"

@@ -70,6 +70,15 @@ BLA_API bla_status bla_event_destroy(void* ev);
 BLA_API bla_status bla_event_record(void* ev, void* stream);
 BLA_API bla_status bla_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* syncs on ev_stop */
 
+/* Launch-bound sequences (one image through a U-Net block is a dozen launches of a few microseconds): record any sequence of
+ * bla_* calls issued on `stream` between begin and end into a hipGraph and replay it with one launch.  Run the sequence once
+ * eagerly first -- scratch buffers and gather tables are created on first use, and allocating is not allowed while recording.
+ * The recorded calls are not executed during recording; pointers and sizes are frozen into the graph. */
+BLA_API bla_status bla_graph_begin(void* stream);
+BLA_API bla_status bla_graph_end(void* stream, void** graph);
+BLA_API bla_status bla_graph_launch(void* graph, void* stream);
+BLA_API bla_status bla_graph_destroy(void* graph);
+
 /* ---- GEMM: replaces matrix_multiply_inplace / matrix_multiply (lib/matrix.c:35-57)
  * and every matrix_transpose + multiply + transpose-back sandwich around it
  * (model/mnist_nn.c:267-292, lib/conv.c:221-227) via transa/transb.

@@ -5,6 +5,7 @@ Tolerance (SURVEY 8c / DESIGN.md): fp32 MFMA vs the fp64 reference,
     normwise   ||C - ref||_F / ||ref||_F <= 1e-5
     elementwise |C - ref|_ij <= 1e-5 * (|A| |B|)_ij   (guards cancellation near zero)
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -281,3 +282,27 @@ def test_gemm_pair_shares_one_launch(dev, ora):
     c1, c2 = dev.zeros((128, 256)), dev.zeros((256, 256))
     nat.gemm_pair(nat.gemm_desc(a1, b1, c1, transb=True), nat.gemm_desc(a2, b2, c2, transa=True))
     assert "pair_nt+tn" in dev.lib().bla_gemm_last_kernel().decode()
+
+
+def test_recorded_sequence_replays_on_new_data(dev, ora):
+    """bla_graph_*: a product with a bias/ReLU epilogue followed by a scale, recorded once and replayed after the inputs changed."""
+    L, chk = dev.lib(), dev.native.check
+    st = L.bla_default_stream()
+    m, k, n = 96, 200, 130
+    a = dev.to_device(uniform(1, (m, k), dtype=np.float32)); b = dev.to_device(uniform(2, (k, n), dtype=np.float32))
+    bias = dev.to_device(uniform(3, (m,), dtype=np.float32)); c = dev.zeros((m, n))
+
+    def seq():
+        dev.gemm(a, b, c, bias_row=bias, act=dev.native.ACT_RELU, stream=st)
+        chk(L.bla_scale_f32(st, c.ptr, m * n, 0.5))
+    seq(); dev.native.sync(st)
+    g = C.c_void_p()
+    chk(L.bla_graph_begin(st)); seq(); chk(L.bla_graph_end(st, C.byref(g)))
+    for seed in (10, 20):
+        a2 = uniform(seed, (m, k), dtype=np.float32); b2 = uniform(seed + 1, (k, n), dtype=np.float32)
+        a.copy_from(a2); b.copy_from(b2)
+        chk(L.bla_graph_launch(g, st)); dev.native.sync(st)
+        want = 0.5 * np.maximum(a2.astype(np.float64) @ b2.astype(np.float64) + bias.numpy().astype(np.float64)[:, None], 0)
+        bound = np.abs(a2).astype(np.float64) @ np.abs(b2).astype(np.float64) + 1
+        assert np.all(np.abs(c.numpy() - want) <= 1e-5 * bound)
+    chk(L.bla_graph_destroy(g))

@@ -15,6 +15,14 @@ e0, e1 = C.c_void_p(), C.c_void_p(); chk(L.bla_event_create(C.byref(e0))); chk(L
 F32 = np.float32
 
 
+def graphed(fn):
+    """fn's launches recorded once (after an eager run has created scratch and tables), replayed with one graph launch"""
+    fn(); pkg.native.sync(st)
+    g = C.c_void_p()
+    chk(L.bla_graph_begin(st)); fn(); chk(L.bla_graph_end(st, C.byref(g)))
+    return lambda: chk(L.bla_graph_launch(g, st))
+
+
 def timeit(fn, iters=20):
     fn(); fn()
     chk(L.bla_event_record(e0, st))
@@ -50,8 +58,10 @@ for (cin, cout, hh) in [(3, 128, 32), (128, 128, 32), (256, 128, 32), (256, 256,
     bwd = lambda: chk(L.bla_resnet_backward_f32(st, D["del_out"].ptr, D["x"].ptr, D["temb"].ptr, C.byref(params), C.byref(ws), C.byref(grads), C.byref(scratch),
                                                 del_x.ptr, hh, hh, cin, cout, 3, tdim, gs))
     tf, tb = timeit(fwd), timeit(bwd)
+    tfg, tbg = timeit(graphed(fwd)), timeit(graphed(bwd))
     fl = 2.0 * hh * hh * 9 * (cin * cout + cout * cout) + (2.0 * hh * hh * cin * cout if cin != cout else 0)   # conv products, forward
-    line = f"{cin:>3}->{cout:<3} {hh:>2}x{hh:<2}  fwd {tf*1e6:7.1f} us ({fl/tf/1e12:5.2f} TF/s)  bwd {tb*1e6:7.1f} us ({2*fl/tb/1e12:5.2f} TF/s)"
+    line = (f"{cin:>3}->{cout:<3} {hh:>2}x{hh:<2}  fwd {tf*1e6:7.1f} us, as one graph {tfg*1e6:7.1f} us ({fl/tfg/1e12:5.2f} TF/s)  "
+            f"bwd {tb*1e6:7.1f} us, as one graph {tbg*1e6:7.1f} us ({2*fl/tbg/1e12:5.2f} TF/s)")
     if cin * cout * hh * hh <= 256 * 256 * 64:
         J = {k: (v.astype(np.float64) if v is not None else None) for k, v in I.items()}
         t0 = time.perf_counter(); f = oracle.resnet_forward(J["x"], J["temb"], J["k1"], J["k2"], J["tw"], J["tb"], J["kres"], dropped.reshape(-1).astype(np.uint8), gs); tcf = time.perf_counter() - t0
@@ -78,4 +88,5 @@ for (c, hh) in [(256, 16), (256, 4)]:
     bwd = lambda: chk(L.bla_attention_backward_f32(st, dev["dy"].ptr, dev["x"].ptr, dev["wq"].ptr, dev["wk"].ptr, dev["wv"].ptr, dev["w"].ptr, C.byref(fws), C.byref(gws),
                                                    outs["del_wq"].ptr, outs["del_wk"].ptr, outs["del_wv"].ptr, outs["del_w"].ptr, outs["del_x"].ptr, c, s, d, 0))
     tf, tb = timeit(fwd), timeit(bwd)
-    print(f"C={c} S={s:<3}  fwd {tf*1e6:7.1f} us  bwd {tb*1e6:7.1f} us", flush=True)
+    tfg, tbg = timeit(graphed(fwd)), timeit(graphed(bwd))
+    print(f"C={c} S={s:<3}  fwd {tf*1e6:7.1f} us, as one graph {tfg*1e6:7.1f} us   bwd {tb*1e6:7.1f} us, as one graph {tbg*1e6:7.1f} us", flush=True)
