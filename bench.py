@@ -199,8 +199,8 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)   # ~50 ms of launches: with 10 the clocks are still ramping inside the timed region (140 vs 143 TFLOP/s)
     ap.add_argument("--size", type=int, default=4096, help="square GEMM size (BASELINE configs[1]: 1024..8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mnist-steps", type=int, default=300, help="timed steps of the secondary MNIST-NN workload (0 = skip)")
