@@ -517,7 +517,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	// Measured and not kept (4096^3 / 8192^3 stayed at 143 / 145 TFLOP/s, 2048^3 lost 10 %): (a) a one-off s_sleep of half a
 	// slab period for the wave in the odd hardware slot, to de-phase co-resident workgroups; (b) sched_group_barrier
 	// interleaving of one ds_read / one DMA per MFMA gap instead of the clump after the barrier; (c) s_setprio 3 around the
-	// read / DMA clump so that the wave issuing memory operations wins arbitration over its co-resident wave's MFMAs.  PMC: MFMA pipe 93 % busy at
+	// read / DMA clump so that the wave issuing memory operations wins arbitration over its co-resident wave's MFMAs; (d) one-wave
+	// workgroups on 64x64 tiles (no cross-wave barrier at all, every wave streams its own operands): 74 TFLOP/s.
+	// A launch that issues nothing but independent 32x32x2 MFMAs reaches 155.2 TFLOP/s (tools/mfma_peak.py): that, not 157.3, is the ceiling.  PMC: MFMA pipe 93 % busy at
 	// 2.38 GHz with two workgroups per CU, 87 % with one -- the residue tracks the LDS-DMA issue cost (4 per 32 MFMAs per wave).
 	// One pipeline step on slab kt (fragments in P); slab kt+1 must exist.  No branch touches the fragment
 	// registers (a conditional around the reads would make hipcc copy them at the join and wait for them).

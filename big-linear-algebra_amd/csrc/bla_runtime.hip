@@ -55,6 +55,26 @@ bla_status ensure_workspace(size_t bytes, void** out) {
 
 using namespace bla;
 
+namespace bla {
+typedef float mfma_acc_t __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(1024) mfma_rate_kernel(int iters, float* sink) {
+	mfma_acc_t c0, c1, c2, c3;   // four independent chains (64 AGPRs: fits 4 waves per SIMD)
+#pragma unroll
+	for (int r = 0; r < 16; r++) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
+	float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
+	for (int it = 0; it < iters; it++) {   // written out as asm so that the chains stay exactly as they are; 8 MFMAs per trip
+		asm volatile("v_mfma_f32_32x32x2_f32 %0, %4, %5, %0\n\tv_mfma_f32_32x32x2_f32 %1, %4, %5, %1\n\t"
+		             "v_mfma_f32_32x32x2_f32 %2, %4, %5, %2\n\tv_mfma_f32_32x32x2_f32 %3, %4, %5, %3\n\t"
+		             "v_mfma_f32_32x32x2_f32 %0, %4, %5, %0\n\tv_mfma_f32_32x32x2_f32 %1, %4, %5, %1\n\t"
+		             "v_mfma_f32_32x32x2_f32 %2, %4, %5, %2\n\tv_mfma_f32_32x32x2_f32 %3, %4, %5, %3"
+		             : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a), "v"(b));
+	}
+	asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results are read by VALU below: software-managed hazard
+	float t = c0[0] + c1[0] + c2[0] + c3[0];
+	if (t == 123.456f) sink[0] = t;   // keep the accumulators live
+}
+}  // namespace bla
+
 extern "C" {
 
 int bla_device_count(void) {
@@ -263,6 +283,17 @@ bla_status bla_graph_destroy(void* graph) {
 	(void)hipGraphExecDestroy(bg->exec);
 	(void)hipGraphDestroy(bg->graph);
 	delete bg;
+	return BLA_OK;
+}
+
+/* Diagnostics: a workgroup of `waves` wavefronts issues `iters` x 8 independent v_mfma_f32_32x32x2_f32 with no memory traffic at all:
+ * the rate this reaches is the practical ceiling of the fp32 MFMA pipe (clock and issue gaps included) that a GEMM can approach. */
+bla_status bla_diag_mfma_rate(void* stream, int blocks, int waves, int iters, float* d_sink) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(blocks > 0 && waves > 0 && waves <= 16 && iters > 0 && d_sink, BLA_ERR_INVALID, "bad argument");
+	hipLaunchKernelGGL(bla::mfma_rate_kernel, dim3(blocks), dim3(waves * 64), 0, pick_stream(stream), iters, d_sink);
+	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
 

@@ -74,6 +74,9 @@ BLA_API bla_status bla_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms
  * bla_* calls issued on `stream` between begin and end into a hipGraph and replay it with one launch.  Run the sequence once
  * eagerly first -- scratch buffers and gather tables are created on first use, and allocating is not allowed while recording.
  * The recorded calls are not executed during recording; pointers and sizes are frozen into the graph. */
+/* diagnostics: `blocks` workgroups of `waves` wavefronts each issue iters x 8 independent fp32 MFMAs (32x32x2) and nothing else --
+ * the practical ceiling of the matrix pipe (tools/mfma_peak.py) */
+BLA_API bla_status bla_diag_mfma_rate(void* stream, int blocks, int waves, int iters, float* d_sink);
 BLA_API bla_status bla_graph_begin(void* stream);
 BLA_API bla_status bla_graph_end(void* stream, void** graph);
 BLA_API bla_status bla_graph_launch(void* graph, void* stream);
