@@ -57,7 +57,7 @@ def build_hip(force=False, verbose=False):
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
             cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                   "-DBLA_BUILDING", "-I", INCLUDE, "-c", s, "-o", o]
+                   "-DBLA_BUILDING", "-I", INCLUDE, "-c", s, "-o", o] + os.environ.get("BLA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DBLA_WSK_DIAG
             jobs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
     for s, p, cmd in jobs:
         out, _ = p.communicate()

@@ -519,7 +519,12 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	// interleaving of one ds_read / one DMA per MFMA gap instead of the clump after the barrier; (c) s_setprio 3 around the
 	// read / DMA clump so that the wave issuing memory operations wins arbitration over its co-resident wave's MFMAs; (d) one-wave
 	// workgroups on 64x64 tiles (no cross-wave barrier at all, every wave streams its own operands): 74 TFLOP/s.
-	// A launch that issues nothing but independent 32x32x2 MFMAs reaches 155.2 TFLOP/s (tools/mfma_peak.py): that, not 157.3, is the ceiling.  PMC: MFMA pipe 93 % busy at
+	// A launch that issues nothing but independent 32x32x2 MFMAs reaches 155.2 TFLOP/s (tools/mfma_peak.py): that, not 157.3, is the ceiling.
+	// Where the rest goes (this kernel rebuilt with pieces compiled out, 4096^3 / 8192^3): as is 143 / 145; without the DMA 146 / 151;
+	// without DMA and barrier 149 / 152; without LDS reads as well 150 / 153 -- the exposed cost is the DMA, not the barrier or the reads.
+	// (e) Fetching TWO slabs ahead (three buffers, s_waitcnt vmcnt(4) for the older batch only, fragment reads written as asm so that
+	// hipcc does not put vmcnt(0) in front of them): correct, 113 / 117 TFLOP/s -- also with vmcnt(0) and with compiler-visible reads,
+	// i.e. it is the second batch in flight per wave that hurts (64 outstanding 1-KiB DMA instructions per CU instead of 32), not the wait.  PMC: MFMA pipe 93 % busy at
 	// 2.38 GHz with two workgroups per CU, 87 % with one -- the residue tracks the LDS-DMA issue cost (4 per 32 MFMAs per wave).
 	// One pipeline step on slab kt (fragments in P); slab kt+1 must exist.  No branch touches the fragment
 	// registers (a conditional around the reads would make hipcc copy them at the join and wait for them).

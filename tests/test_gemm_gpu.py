@@ -71,7 +71,7 @@ def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     shapes = [(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128), (257, 100, 31), (200, 260, 136)]
     if 3 <= cfg <= 5 or cfg >= 7:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
-                  (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128)]
+                  (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128), (132, 112, 140), (128, 144, 128)]
         if cfg in (5, 10):   # BK = 32, or the persistent kernel's even slab count
             shapes = [s for s in shapes if s[1] % 32 == 0]
     try:
