@@ -57,6 +57,7 @@ struct GemmArgs {
 	const float* g_img; const float* g_zero;
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
+	int rc_global;   // host-side only: pick the instantiation that fetches row-contiguous operands with global_load_lds
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
@@ -275,7 +276,7 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && BN == 128 && BK == 16 && WM * WN == 4),
 	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image, mode 4 gathers A and takes a K-contiguous B");
@@ -396,6 +397,23 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 
 	typedef __attribute__((address_space(3))) void* lds_ptr_t;
 	typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+	// Which operands go through buffer_load ... lds (SGPR descriptor + 32-bit lane offset + scalar slab offset) instead of
+	// global_load_lds (64-bit pointer per lane): always the K-contiguous ones (NT 4096^3: 142 vs 115 TFLOP/s); the row-contiguous
+	// ones too unless the host picks the RCG instantiation -- the buffer form holds 139-147 TFLOP/s across 5120^3 / 6144^3 / 8192^3
+	// where the global form drops to 128, but on power-of-two pitches up to 16 KiB the global form is 1-4 % ahead (4096^3: 142.7 vs 141.0).
+	// Compile-time: choosing between the two forms at run time inside the loop costs 4 %.
+	constexpr bool BUF_OK = GATHER == 0 && !PERSIST;   // (the persistent variant re-bases its pointers per tile)
+	constexpr bool A_BUF = BUF_OK && (AKC || !RCG), B_BUF = BUF_OK && (BKC || !RCG);
+#if defined(__HIP_DEVICE_COMPILE__)
+	// raw descriptors, no bounds (rows / columns past the matrix are fetched from clamped offsets); lane offsets in bytes
+	__amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7fffffff, 0x00020000);
+	__amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7fffffff, 0x00020000);
+	int voff_a[A_NI], voff_b[B_NI], soff_a = 0, soff_b = 0;
+#pragma unroll
+	for (int i = 0; i < A_NI; i++) voff_a[i] = A_BUF ? (int)((ga[i] - p.A) * 4) : 0;
+#pragma unroll
+	for (int i = 0; i < B_NI; i++) voff_b[i] = B_BUF ? (int)((gb[i] - p.B) * 4) : 0;
+#endif
 	auto dma = [&](int buf) {
 		float* base = lds + buf * (A_SZ + B_SZ);
 		if (GATHER == 4) {
@@ -418,6 +436,23 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			}
 			return;
 		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (GATHER == 0) {   // dense operands
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) {
+				if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
+				else { __builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0); ga[i] += a_step; }
+			}
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) {
+				if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
+				else { __builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0); gb[i] += b_step; }
+			}
+			if (A_BUF) soff_a += (int)(a_step * 4);
+			if (B_BUF) soff_b += (int)(b_step * 4);
+			return;
+		}
+#endif
 #pragma unroll
 		for (int i = 0; i < A_NI; i++) {
 			__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
@@ -1066,9 +1101,9 @@ template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bo
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 	size_t lds_bytes = NBUF * (BM + BN) * BK * sizeof(float);
 	dim3 block(WM * WN * 64);
-#define BLA_LAUNCH(AK, BK_)                                                                                 \
+#define BLA_LAUNCH2(AK, BK_, RG)                                                                            \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST>;                 \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST, 0, RG>;          \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -1076,10 +1111,16 @@ static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, 
 		hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, a);                                             \
 		return hipGetLastError();                                                                           \
 	} while (0)
+#define BLA_LAUNCH(AK, BK_)                                                                                 \
+	do {                                                                                                    \
+		if (!((AK) && (BK_)) && a.rc_global && NBUF == 2 && !PERSIST) BLA_LAUNCH2(AK, BK_, true);           \
+		BLA_LAUNCH2(AK, BK_, false);                                                                        \
+	} while (0)
 	if (akc && !bkc) BLA_LAUNCH(true, false);
 	if (akc && bkc) BLA_LAUNCH(true, true);
 	if (!akc && !bkc) BLA_LAUNCH(false, false);
 	BLA_LAUNCH(false, true);
+#undef BLA_LAUNCH2
 #undef BLA_LAUNCH
 }
 
@@ -1192,6 +1233,10 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 	a.pre_act = ep ? ep->pre_act : nullptr; a.ld_pre = ep ? ep->ld_pre : 0; a.act = ep ? ep->act : BLA_ACT_NONE;
 	a.relu_mask = ep ? ep->relu_mask : nullptr; a.ld_mask = ep ? ep->ld_mask : 0;
 	a.row_sum_a = ep ? ep->row_sum_a : nullptr;
+	{   // row-contiguous operand pitches that are powers of two up to 16 KiB: global_load_lds measured ahead (see the kernel)
+		auto pow2_small = [](int ld) { return ld > 0 && (ld & (ld - 1)) == 0 && ld <= 4096; };
+		a.rc_global = (transa ? pow2_small(lda) : true) && (!transb ? pow2_small(ldb) : true);
+	}
 	a.softmax_y = ep ? ep->softmax_y : nullptr; a.softmax_scale = ep ? ep->softmax_scale : 0.f; a.softmax_grad = ep ? ep->softmax_grad : nullptr;
 	BLA_REQUIRE(!a.row_sum_a || !transa, BLA_ERR_INVALID, "row_sum_a needs a non-transposed A");
 	BLA_REQUIRE((a.softmax_y == nullptr) == (a.softmax_grad == nullptr), BLA_ERR_INVALID, "softmax_y and softmax_grad go together");
@@ -1214,13 +1259,22 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		// A CU retires 256 fp32 MFMA FLOP/clk whatever the wave count (measured: 8 or 16 waves per tile only add
 		// overhead), so a tile costs ~8*K cycles; beyond K ~ 1024 splitting K over workgroups (tiled path) wins.
 		if (((!big && tiles32 <= 512 && k <= 1280) || a.softmax_grad) && k > 0) cfg = 6;
-		// NT (both operands K-contiguous) on 4096^3 / 8192^3: 256x128 three-buffer DMA kernel 138.7 / 142.1 TFLOP/s, register-staged
-		// BK=32 kernel 130, 128x128 DMA kernel 116 / 119; at 2048^3 the 128x128 DMA kernel leads (126 vs 104), so only products with
-		// at least one 256x128 tile per resident slot (2 per CU) take the big tile.
-		else if (akc && bkc && vec_ok && k % 16 == 0 && (long)((m + 255) / 256) * ((n + 127) / 128) >= 2 * cus) cfg = 9;
-		else if (vec_ok && k % 16 == 0 && k > 0) {                      // direct-to-LDS fast path; tile by how many tiles the chip gets:
-			long t128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);   // 128x128 once there are >= 2 per CU, 128x64 when that still gives
-			cfg = big_tiles >= 2 * cus ? 3 : (t128x64 >= cus ? 7 : 4);  // >= 1 per CU (2048^3: 132 vs 122 TFLOP/s), else 64x64
+		else if (vec_ok && k % 16 == 0 && k > 0) {
+			// Direct-to-LDS family; tile by a small cost model of the residency rounds: a CU works through ceil(tiles / CUs) tiles, a tile
+			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
+			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
+			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
+			const int cand[3] = {3, 7, 4};
+			const double eff[3] = {1.0, 0.95, 0.87};
+			double best = 0;
+			for (int i = 0; i < 3; i++) {
+				const Config& cc = kConfigs[cand[i]];
+				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
+				long rounds = (t + cus - 1) / cus;
+				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
+				if (t < 2L * cus) cost /= 0.88;
+				if (i == 0 || cost < best) { best = cost; cfg = cand[i]; }
+			}
 		}
 		else cfg = big ? 0 : 1;
 	}
