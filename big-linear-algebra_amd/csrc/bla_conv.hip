@@ -439,7 +439,9 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		const int2* ptab;
 		bla_status st = get_pixel_table(s, a.g, &ptab);
 		if (st) return st;
-		if (MODE == CONV_FWD && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w) {
+		// (the padded-copy kernels address the copy with 32-bit byte offsets: at most 2 GiB of it, and of del_y)
+		const bool fits32 = (long)batch * a.g.c * (a.g.h + a.g.k - 1) * (a.g.w + a.g.k - 1) < (1L << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
+		if (MODE == CONV_FWD && fits32 && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w) {
 			// stride 1: pad once, then the B slab is fetched with the same 16-byte DMA as a dense operand
 			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
 			void* ws;
@@ -454,7 +456,7 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
-		if (MODE == CONV_WGRAD && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w && a.N % 4 == 0) {
+		if (MODE == CONV_WGRAD && fits32 && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w && a.N % 4 == 0) {
 			// stride 1: transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
 			const size_t slab_bytes = (size_t)gather_gemm_splits(4, batch, a.N, a.M) * a.M * a.N * sizeof(float);

@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	// where the global form drops to 128, but on power-of-two pitches up to 16 KiB the global form is 1-4 % ahead (4096^3: 142.7 vs 141.0).
 	// Compile-time: choosing between the two forms at run time inside the loop costs 4 %.
 	constexpr bool BUF_OK = GATHER == 0 && !PERSIST;   // (the persistent variant re-bases its pointers per tile)
-	constexpr bool A_BUF = BUF_OK && (AKC || !RCG), B_BUF = BUF_OK && (BKC || !RCG);
+	constexpr bool A_BUF = (BUF_OK && (AKC || !RCG)) || GATHER == 3, B_BUF = (BUF_OK && (BKC || !RCG)) || GATHER == 4;   // padded-copy conv modes: their dense operand too
 #if defined(__HIP_DEVICE_COMPILE__)
 	// raw descriptors, no bounds (rows / columns past the matrix are fetched from clamped offsets); lane offsets in bytes
 	__amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7fffffff, 0x00020000);
@@ -416,26 +416,26 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 #endif
 	auto dma = [&](int buf) {
 		float* base = lds + buf * (A_SZ + B_SZ);
-		if (GATHER == 4) {
-			const float* ib = p.g_img + g_img * p.g_img_stride;
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (GATHER == 4) {   // dense operand (del_y) through buffer_load ... lds
+			const float* ib = p.g_img + g_img * p.g_img_stride;   // gathered operand: global_load_lds (its 16-byte chunks are mostly unaligned;
+#pragma unroll                                          // the buffer form measured slower for them: 254 vs 230 us forward at 128->128 @32x32 x64)
 			for (int i = 0; i < A_NI; i++) {
 				const float* src = ib + (g4_tap[i] + p.g_ktab[g_r + g4_chunk[i]].x);
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 			}
 #pragma unroll
-			for (int i = 0; i < B_NI; i++) {
-				__builtin_amdgcn_global_load_lds((gbl_ptr_t)gb[i], (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
-				gb[i] += b_step;
-			}
+			for (int i = 0; i < B_NI; i++)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
+			soff_b += BK * 4;
 			g_r += BK;
-			if (g_r >= p.g_HWo) {
+			if (g_r >= p.g_HWo) {   // next image: del_y [image][N][HWo]
 				g_r = 0; g_img++;
-#pragma unroll
-				for (int i = 0; i < B_NI; i++) gb[i] += (size_t)(p.N - 1) * p.g_HWo;
+				soff_b += (p.N - 1) * p.g_HWo * 4;
 			}
 			return;
 		}
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (GATHER == 0) {   // dense operands
 #pragma unroll
@@ -453,10 +453,20 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			return;
 		}
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (A_BUF) {   // mode 3: the dense kernels operand
 #pragma unroll
-		for (int i = 0; i < A_NI; i++) {
-			__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
-			ga[i] += a_step;
+			for (int i = 0; i < A_NI; i++)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
+			soff_a += (int)(a_step * 4);
+		} else
+#endif
+		{
+#pragma unroll
+			for (int i = 0; i < A_NI; i++) {
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)ga[i], (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+				ga[i] += a_step;
+			}
 		}
 		if (GATHER == 3) {
 #pragma unroll
@@ -1154,7 +1164,7 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	BLA_REQUIRE(mode != 4 || M % 4 == 0, BLA_ERR_INVALID, "mode 4 needs a tap count that is a multiple of 4");
 	BLA_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && ((mode != 2 && mode != 4) || HWo % 16 == 0), BLA_ERR_INVALID,
 	            "gathered product needs K %% 16 == 0 and a 16-byte aligned dense operand (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
-	BLA_REQUIRE((long)batch * img_stride < (1L << 31) && (long)N < (1L << 31), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
+	BLA_REQUIRE((long)batch * img_stride < (mode >= 3 ? (1L << 29) : (1L << 31)) && (long)N < (1L << 31), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
 	GemmArgs a = {};
 	a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
 	if (mode == 4) { a.A = nullptr; a.lda = 0; a.B = A; a.ldb = lda; }      // the dense operand (del_y) is the K-contiguous B
