@@ -573,6 +573,38 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	// 2.38 GHz with two workgroups per CU, 87 % with one -- the residue tracks the LDS-DMA issue cost (4 per 32 MFMAs per wave).
 	// One pipeline step on slab kt (fragments in P); slab kt+1 must exist.  No branch touches the fragment
 	// registers (a conditional around the reads would make hipcc copy them at the join and wait for them).
+	// One-workgroup-per-CU tile (256x256: a wave holds 16 accumulator blocks = 256 AGPRs, and there is no second workgroup to fill
+	// the matrix pipe while this one reads and fetches).  Two things change against the pipeline below:
+	//  * fragments are held per k-HALF of a slab, not per slab: P = k-half 0, Q = k-half 1 (32 registers each instead of 2 x 64);
+	//    Q of slab t is read under the MFMAs of P, P of slab t+1 under the MFMAs of Q -- so the wait + barrier for slab t+1 sits in
+	//    the MIDDLE of slab t, and the roles of P and Q never swap (no unrolling by two);
+	//  * every LDS read and DMA instruction is dealt out BETWEEN MFMAs (one read unit per 8 or 2 MFMAs, one DMA per 2) instead of
+	//    standing in a clump behind the barrier.  All LDS reads of a phase come before its first DMA: hipcc waits for vmcnt(0) in
+	//    front of any LDS read that follows an LDS-DMA.
+	constexpr bool HALFSLAB = TM == 4 && TN == 4 && KK == 2 && A_NI + B_NI == 8 && GATHER == 0 && !PERSIST && NBUF == 2;
+	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
+#if defined(__HIP_DEVICE_COMPILE__)
+	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab (dense operands); the offsets advance in dma_advance()
+		float* base = lds + buf * (A_SZ + B_SZ);
+		if (d < A_NI) {
+			const int i = d;
+			if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
+			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + g_adv_a), (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+		} else {
+			const int i = d - A_NI;
+			if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
+			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb[i] + g_adv_b), (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
+		}
+	};
+	auto dma_advance = [&](bool really) {   // uniform select, no branch: past the last slab the cursor stays on it (harmless re-fetch)
+		const int sa = really ? (int)(a_step * 4) : 0, sb = really ? (int)(b_step * 4) : 0;
+		if (A_BUF) soff_a += sa; else g_adv_a += really ? a_step : 0;
+		if (B_BUF) soff_b += sb; else g_adv_b += really ? b_step : 0;
+	};
+#else
+	auto dma_one = [&](int, int) {};
+	auto dma_advance = [&](bool) {};
+#endif
 	auto step = [&](int kt, bool do_dma, float (&pa)[KK][TM][4], float (&pb)[KK][TN][4], float (&qa)[KK][TM][4], float (&qb)[KK][TN][4]) {
 		// sched_barrier(0) pins the order: hipcc otherwise floats the MFMAs (which touch no memory) across the
 		// barrier and the waits, e.g. hoisting the NEXT step's vmcnt(0)+barrier above this step's MFMAs.
@@ -626,6 +658,54 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			}
 			return;
 		}
+		if (HALFSLAB || (m0 + BM <= p.M && n0 + BN <= p.N && p.splits == 1)) {   // (the 256x256 variant is only launched on whole tiles)
+			// interior tile: no per-element bounds branch (with 256 accumulators per lane hipcc otherwise parks them all in scratch
+			// and reloads them one by one behind each branch); one block at a time
+			if constexpr (HALFSLAB) {
+				// block (im, in), register r of lane (l31, h): row index inside the block i = (r&3) + 8*(r>>2) + 4h, column index l31.
+				// K-contiguous operand: block b owns rows / columns w0 + 32 b + index; row-contiguous: w0 + 4 index + b.
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) {
+						const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+						const int row = m0 + wm0 + (AKC ? im * 32 + i : 4 * i + im);
+						float* cp = p.C + (size_t)row * p.ldc + n0 + wn0;
+						if (BKC) {
+#pragma unroll
+							for (int in = 0; in < TN; in++) cp[in * 32 + l31] = p.alpha * acc[im][in][r];
+						} else {   // four consecutive columns per lane
+							*reinterpret_cast<float4*>(cp + 4 * l31) =
+								make_float4(p.alpha * acc[im][0][r], p.alpha * acc[im][1][r], p.alpha * acc[im][2][r], p.alpha * acc[im][3][r]);
+						}
+					}
+				return;
+			}
+			if (!p.bias_row && !p.bias_col && !p.pre_act && p.act == BLA_ACT_NONE && !p.relu_mask && p.beta == 0.f) {   // plain C = alpha * acc
+				// (the 256x256 variant is only launched with a plain epilogue: any other path in this function makes hipcc park its 256
+				// accumulators in scratch at the loop exit)
+#pragma unroll
+				for (int im = 0; im < TM; im++)
+#pragma unroll
+					for (int in = 0; in < TN; in++) {
+						float* cp = p.C + (size_t)(m0 + wm0 + im * 32 + 4 * h) * p.ldc + n0 + wn0 + in * 32 + l31;
+#pragma unroll
+						for (int r = 0; r < 16; r++) cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = p.alpha * acc[im][in][r];
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				return;
+			}
+#pragma unroll
+			for (int im = 0; im < TM; im++)
+#pragma unroll
+				for (int in = 0; in < TN; in++) {
+					const int col = n0 + wn0 + in * 32 + l31;
+#pragma unroll
+					for (int r = 0; r < 16; r++) epilogue_store(p, m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col, acc[im][in][r]);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			return;
+		}
 #pragma unroll
 		for (int im = 0; im < TM; im++)
 #pragma unroll
@@ -641,6 +721,110 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 				}
 			}
 	};
+
+	if constexpr (HALFSLAB) {
+		// Fragment reads are written as asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it can see after an LDS-DMA, and
+		// in a loop the reads of a slab's first phase always follow the DMA instructions of the previous slab's second phase -- every
+		// slab would start by waiting for a fetch issued half a microsecond earlier.  The asm reads are invisible to that rule; their
+		// results are tied to an explicit s_waitcnt lgkmcnt(0) ("land") in front of their first MFMA.
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		typedef float v2f __attribute__((ext_vector_type(2)));
+		typedef __attribute__((address_space(3))) float* lds_f;
+		const unsigned lds0 = (unsigned)(size_t)(lds_f)lds;
+		constexpr unsigned BUF_BYTES = (A_SZ + B_SZ) * 4;
+		// K-contiguous operand: block x of k-half kk = 16 bytes at row w0 + x*32 + l31, chunk kk*2 + h (x only adds a multiple of 2048 bytes).
+		// Row-contiguous operand: its four blocks do not own 32 consecutive rows each but the rows w0 + 4*lane + block -- then ONE 16-byte
+		// read at (k, w0 + 4*l31) delivers a lane's element of all four blocks for that k (instead of four dwords), and in the output a lane
+		// holds four consecutive columns (16-byte stores).  Which rows / columns a block owns is a free choice: only the epilogue's index map changes.
+		unsigned a_ad[2], b_ad[2];
+#pragma unroll
+		for (int kk = 0; kk < 2; kk++) {
+			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + 4 * l31) * 4;
+			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + 4 * l31)) * 4;
+		}
+		struct Frag {
+			v4f a[4], b[4];   // K-contiguous: [block], elements = k-offset j; row-contiguous: [k-offset j], elements = block
+		};
+		Frag P, Q;
+		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.a[im][j] : f.a[j][im]; };
+		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.b[in][j] : f.b[j][in]; };
+		auto mf1 = [&](const Frag& f, int idx) {   // idx-th of the 64 MFMAs of a k-half: j-major, then im, in
+			const int j = idx / 16, im = (idx % 16) / 4, in = idx % 4;
+			acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(f, im, j), opb(f, in, j), acc[im][in], 0, 0, 0);
+		};
+		auto read_unit = [&](unsigned buf, int kk, int u, Frag& f) {   // units 0..3: A side, 4..7: B side
+			const int x = u & 3;
+			if (u < 4) {
+				const unsigned ad = buf + a_ad[kk];
+				if (AKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[x]) : "v"(ad), "n"(x * BM * 4));
+			} else {
+				const unsigned ad = buf + b_ad[kk];
+				if (BKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[x]) : "v"(ad), "n"(x * BN * 4));
+			}
+		};
+		auto land = [&](Frag& f) {   // every read into f has returned; later uses of f depend on this statement
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
+		};
+		// slab t in buffer t&1.  One uniform body for every slab: past the end the fetch cursor stays on the last slab (re-fetched
+		// into a buffer nobody reads again) and the "next" fragments are stale LDS that is never multiplied -- so there is no tail
+		// code, no branch in the loop, and the 256 accumulators never leave their registers.
+		int fetched = 0;                       // slabs the cursor has been advanced past
+		auto fetch_slab = [&](int buf) {       // prologue form (clumped)
+#pragma unroll
+			for (int d = 0; d < 8; d++) dma_one(buf, d);
+			const bool adv = fetched + 1 < nkt;
+			dma_advance(adv); fetched += adv ? 1 : 0;
+		};
+		auto slab = [&](int t) {
+			const unsigned cur = (t & 1) * BUF_BYTES, nxt = ((t + 1) & 1) * BUF_BYTES;
+			// phase A: k-half 0 from P; k-half 1 of this slab -> Q, one read unit per 8 MFMAs
+			land(P);
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				read_unit(cur, 1, u, Q);
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int m = 0; m < 8; m++) mf1(P, u * 8 + m);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			// phase B: slab t+1 has landed for everyone, and everyone is done reading slab t
+			land(Q);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+#pragma unroll
+			for (int u = 0; u < 8; u++) {     // k-half 0 of slab t+1 -> P (P's last use was phase A), one read unit per 2 MFMAs
+				read_unit(nxt, 0, u, P);
+				__builtin_amdgcn_sched_barrier(0);
+				mf1(Q, 2 * u); mf1(Q, 2 * u + 1);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+#pragma unroll
+			for (int d = 0; d < 8; d++) {     // slab t+2 -> this slab's buffer, one DMA per 2 MFMAs
+				dma_one(t & 1, d);
+				__builtin_amdgcn_sched_barrier(0);
+				mf1(Q, 16 + 2 * d); mf1(Q, 16 + 2 * d + 1);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			{ const bool adv = fetched + 1 < nkt; dma_advance(adv); fetched += adv ? 1 : 0; }
+#pragma unroll
+			for (int m = 32; m < 64; m++) mf1(Q, m);
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		if (nkt > 0) {
+			fetch_slab(0);
+			fetch_slab(1);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+#pragma unroll
+			for (int u = 0; u < 8; u++) read_unit(0, 0, u, P);
+			for (int t = 0; t < nkt; t++) slab(t);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetches of the last slab
+		}
+		store_tile();
+		return;
+	}
 
 	if constexpr (PERSIST) {
 		// Persistent variant: gridDim.x workgroups (two per CU) walk the tile list with stride gridDim.x and treat the K slabs
@@ -1068,6 +1252,7 @@ static const Config kConfigs[] = {
 	{128, 256, 16, 256, true, "glds128x256x16"},
 	{256, 128, 16, 256, true, "glds256x128x16"},
 	{128, 128, 16, 256, true, "glds128x128x16p"},   // persistent: 2 workgroups per CU walk the tile list, slab stream continuous across tiles
+	{256, 256, 16, 256, true, "glds256x256x16"},    // one workgroup per CU, each wave a 128x128 sub-tile (256 accumulator registers)
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1350,6 +1535,13 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
+	if (cfg == 11) {   // 256x256: whole tiles only (its epilogue has no bounds checks), one pass over K
+		BLA_REQUIRE(m % 256 == 0 && n % 256 == 0 && k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
+		            "gemm config 11 (%s) needs m, n multiples of 256, k >= 32 and a 16-byte aligned C", c.name);
+		BLA_REQUIRE(!a.bias_row && !a.bias_col && !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !deferred_row_sum, BLA_ERR_INVALID,
+		            "gemm config 11 (%s) takes a plain epilogue (alpha only)", c.name);
+		splits = 1;
+	}
 	if (cfg == 10) {   // persistent variant: one pass over K per tile, slab parity must restart with every tile
 		BLA_REQUIRE(k % (2 * c.bk) == 0, BLA_ERR_INVALID, "gemm config 10 (%s) needs k %% %d == 0", c.name, 2 * c.bk);
 		splits = 1;
@@ -1384,10 +1576,11 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		case 7: e = launch_glds<128, 64, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 8: e = launch_glds<128, 256, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;
 		case 9: e = launch_glds<256, 128, 16, 2, 2, 2, 3>(a, akc, bkc, grid, s); break;
-		default: {   // 10
+		case 10: {
 			unsigned tiles = grid.x, cap = 2u * (unsigned)cus;
 			e = launch_glds<128, 128, 16, 2, 2, 1, 2, true>(a, akc, bkc, dim3(tiles < cap ? tiles : cap, 1, 1), s);
 		} break;
+		default: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;   // 11
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
