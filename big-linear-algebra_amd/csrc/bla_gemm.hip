@@ -1459,15 +1459,19 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
 			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
 			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
-			const int cand[3] = {3, 7, 4};
-			const double eff[3] = {1.0, 0.95, 0.87};
+			const int cand[4] = {3, 7, 4, 11};
+			const double eff[4] = {1.0, 0.95, 0.87, 1.03};
+			// 256x256 (config 11): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C only
+			const bool big_ok = m % 256 == 0 && n % 256 == 0 && k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
+			                    !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !a.row_sum_a;
 			double best = 0;
-			for (int i = 0; i < 3; i++) {
+			for (int i = 0; i < (big_ok ? 4 : 3); i++) {
 				const Config& cc = kConfigs[cand[i]];
 				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
 				long rounds = (t + cus - 1) / cus;
 				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
-				if (t < 2L * cus) cost /= 0.88;
+				if (t < 2L * cus && cand[i] != 11) cost /= 0.88;
+				if (cand[i] == 11 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
 				if (i == 0 || cost < best) { best = cost; cfg = cand[i]; }
 			}
 		}
