@@ -308,3 +308,59 @@ def test_recorded_sequence_replays_on_new_data(dev, ora):
         bound = np.abs(a2).astype(np.float64) @ np.abs(b2).astype(np.float64) + 1
         assert np.all(np.abs(c.numpy() - want) <= 1e-5 * bound)
     chk(L.bla_graph_destroy(g))
+
+
+def test_automatic_dispatch_fuzz(dev):
+    """Random shapes, layouts, leading dimensions (sub-matrix views) and epilogues through the AUTOMATIC configuration choice -- whatever
+    kernel the heuristics pick (wave-split-K, the three DMA tiles, the 256x256 kernel on whole tiles, split-K slabs, generic path) must
+    agree with a float64 product.  Dimensions are drawn so that every family is hit, including multiples of 256 with padded pitches."""
+    rng = np.random.default_rng(20250)
+    seen = set()
+    pools = [[1, 3, 17, 33, 64, 100], [128, 200, 256, 260, 384], [512, 768, 1024, 1280], [2048, 2304, 4096]]
+    for case in range(70):
+        cls = rng.integers(0, 4)
+        m = int(rng.choice(pools[cls])); n = int(rng.choice(pools[rng.integers(0, cls + 1)] if cls else pools[0]))
+        if rng.random() < 0.5: m, n = n, m
+        k = int(rng.choice([1, 5, 16, 32, 48, 100, 128, 256, 512, 784]))
+        if m * n * k > 3e9: k = 64
+        ta, tb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        pad_a, pad_b, pad_c = (int(rng.choice([0, 0, 4, 8, 3])) for _ in range(3))
+        ar, ac = (k, m) if ta else (m, k); br, bc = (n, k) if tb else (k, n)
+        A = uniform(1000 + case, (ar, ac + pad_a), dtype=np.float32); B = uniform(2000 + case, (br, bc + pad_b), dtype=np.float32)
+        Cbuf = uniform(3000 + case, (m, n + pad_c), dtype=np.float32)
+        dA, dB, dC = dev.to_device(A), dev.to_device(B), dev.to_device(Cbuf)
+        kw = {}
+        a_eff = A[:, :ac]; b_eff = B[:, :bc]
+        opA = (a_eff.T if ta else a_eff).astype(np.float64); opB = (b_eff.T if tb else b_eff).astype(np.float64)
+        ref = opA @ opB
+        bound = np.abs(opA) @ np.abs(opB)
+        mode = rng.integers(0, 3)
+        alpha = 1.0
+        if mode == 1:      # alpha / beta
+            alpha, beta = 0.5, 2.0
+            kw = dict(alpha=alpha, beta=beta)
+            ref = alpha * ref + beta * Cbuf[:, :n].astype(np.float64); bound = alpha * bound + np.abs(beta * Cbuf[:, :n])
+        elif mode == 2:    # bias + relu
+            bias = uniform(4000 + case, (m,), dtype=np.float32); dbias = dev.to_device(bias)
+            kw = dict(bias_row=dbias, act=dev.native.ACT_RELU)
+            ref = np.maximum(ref + bias.astype(np.float64)[:, None], 0); bound = bound + np.abs(bias)[:, None]
+        dev.gemm(dA, dB, dC, transa=ta, transb=tb, m=m, n=n, k=k, lda=ac + pad_a, ldb=bc + pad_b, ldc=n + pad_c, **kw)
+        name = dev.lib().bla_gemm_last_kernel().decode()
+        seen.add(name.split("_")[2])
+        got = dC.numpy()
+        assert np.all(np.abs(got[:, :n] - ref) <= 1e-5 * bound + 1e-6), (case, m, n, k, ta, tb, mode, name)
+        if pad_c:
+            assert np.array_equal(got[:, n:], Cbuf[:, n:]), ("wrote outside the view", case, name)
+    assert "wsk32x32" in seen and len(seen) >= 4, seen
+    # the 256x256 kernel needs a chip-filling product on whole tiles with a plain epilogue: all four layouts, padded pitches, alpha
+    for ta, tb in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+        m, n, k = 4096, 4096, 80
+        ar, ac = (k, m) if ta else (m, k); br, bc = (n, k) if tb else (k, n)
+        A = uniform(50 + ta, (ar, ac + 8), dtype=np.float32); B = uniform(60 + tb, (br, bc + 4), dtype=np.float32)
+        dA, dB, dC = dev.to_device(A), dev.to_device(B), dev.zeros((m, n + 12))
+        dev.gemm(dA, dB, dC, transa=bool(ta), transb=bool(tb), m=m, n=n, k=k, lda=ac + 8, ldb=bc + 4, ldc=n + 12, alpha=0.25)
+        assert "glds256x256x16" in dev.lib().bla_gemm_last_kernel().decode()
+        opA = (A[:, :ac].T if ta else A[:, :ac]).astype(np.float64); opB = (B[:, :bc].T if tb else B[:, :bc]).astype(np.float64)
+        got = dC.numpy()
+        assert np.all(np.abs(got[:, :n] - 0.25 * (opA @ opB)) <= 1e-5 * (np.abs(opA) @ np.abs(opB))), (ta, tb)
+        assert not got[:, n:].any()
