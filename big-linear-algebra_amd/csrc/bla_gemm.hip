@@ -582,7 +582,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//  * every LDS read and DMA instruction is dealt out BETWEEN MFMAs (one read unit per 8 or 2 MFMAs, one DMA per 2) instead of
 	//    standing in a clump behind the barrier.  All LDS reads of a phase come before its first DMA: hipcc waits for vmcnt(0) in
 	//    front of any LDS read that follows an LDS-DMA.
-	constexpr bool HALFSLAB = TM == 4 && TN == 4 && KK == 2 && A_NI + B_NI == 8 && GATHER == 0 && !PERSIST && NBUF == 2;
+	constexpr bool HALFSLAB = TM == 4 && TN == 4 && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;   // BK = 16 or 32
+	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
 #if defined(__HIP_DEVICE_COMPILE__)
 	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab (dense operands); the offsets advance in dma_advance()
@@ -737,9 +738,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		// Row-contiguous operand: its four blocks do not own 32 consecutive rows each but the rows w0 + 4*lane + block -- then ONE 16-byte
 		// read at (k, w0 + 4*l31) delivers a lane's element of all four blocks for that k (instead of four dwords), and in the output a lane
 		// holds four consecutive columns (16-byte stores).  Which rows / columns a block owns is a free choice: only the epilogue's index map changes.
-		unsigned a_ad[2], b_ad[2];
+		unsigned a_ad[KK], b_ad[KK];
 #pragma unroll
-		for (int kk = 0; kk < 2; kk++) {
+		for (int kk = 0; kk < KK; kk++) {
 			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + 4 * l31) * 4;
 			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + 4 * l31)) * 4;
 		}
@@ -774,35 +775,40 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		int fetched = 0;                       // slabs the cursor has been advanced past
 		auto fetch_slab = [&](int buf) {       // prologue form (clumped)
 #pragma unroll
-			for (int d = 0; d < 8; d++) dma_one(buf, d);
+			for (int d = 0; d < NDMA; d++) dma_one(buf, d);
 			const bool adv = fetched + 1 < nkt;
 			dma_advance(adv); fetched += adv ? 1 : 0;
 		};
 		auto slab = [&](int t) {
 			const unsigned cur = (t & 1) * BUF_BYTES, nxt = ((t + 1) & 1) * BUF_BYTES;
-			// phase A: k-half 0 from P; k-half 1 of this slab -> Q, one read unit per 8 MFMAs
-			land(P);
+			// phases 0 .. KK-2: k-part q from one set while k-part q+1 of this slab is read into the other, one read unit per 8 MFMAs
 #pragma unroll
-			for (int u = 0; u < 8; u++) {
-				read_unit(cur, 1, u, Q);
-				__builtin_amdgcn_sched_barrier(0);
+			for (int q = 0; q + 1 < KK; q++) {
+				Frag& use = (q & 1) ? Q : P;
+				Frag& fill = (q & 1) ? P : Q;
+				land(use);
 #pragma unroll
-				for (int m = 0; m < 8; m++) mf1(P, u * 8 + m);
-				__builtin_amdgcn_sched_barrier(0);
+				for (int u = 0; u < 8; u++) {
+					read_unit(cur, q + 1, u, fill);
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int m = 0; m < 8; m++) mf1(use, u * 8 + m);
+					__builtin_amdgcn_sched_barrier(0);
+				}
 			}
-			// phase B: slab t+1 has landed for everyone, and everyone is done reading slab t
+			// last phase (k-part KK-1 from Q): slab t+1 has landed for everyone, and everyone is done reading slab t
 			land(Q);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 #pragma unroll
-			for (int u = 0; u < 8; u++) {     // k-half 0 of slab t+1 -> P (P's last use was phase A), one read unit per 2 MFMAs
+			for (int u = 0; u < 8; u++) {     // k-part 0 of slab t+1 -> P, one read unit per 2 MFMAs
 				read_unit(nxt, 0, u, P);
 				__builtin_amdgcn_sched_barrier(0);
 				mf1(Q, 2 * u); mf1(Q, 2 * u + 1);
 				__builtin_amdgcn_sched_barrier(0);
 			}
 #pragma unroll
-			for (int d = 0; d < 8; d++) {     // slab t+2 -> this slab's buffer, one DMA per 2 MFMAs
+			for (int d = 0; d < NDMA; d++) {  // slab t+2 -> this slab's buffer, one DMA per 2 MFMAs
 				dma_one(t & 1, d);
 				__builtin_amdgcn_sched_barrier(0);
 				mf1(Q, 16 + 2 * d); mf1(Q, 16 + 2 * d + 1);
@@ -810,7 +816,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			}
 			{ const bool adv = fetched + 1 < nkt; dma_advance(adv); fetched += adv ? 1 : 0; }
 #pragma unroll
-			for (int m = 32; m < 64; m++) mf1(Q, m);
+			for (int m = 16 + 2 * NDMA; m < 64; m++) mf1(Q, m);
 			__builtin_amdgcn_sched_barrier(0);
 		};
 		if (nkt > 0) {
@@ -1254,6 +1260,7 @@ static const Config kConfigs[] = {
 	{256, 128, 16, 256, true, "glds256x128x16"},
 	{128, 128, 16, 256, true, "glds128x128x16p"},   // persistent: 2 workgroups per CU walk the tile list, slab stream continuous across tiles
 	{256, 256, 16, 256, true, "glds256x256x16"},    // one workgroup per CU, each wave a 128x128 sub-tile (256 accumulator registers)
+	{256, 256, 32, 256, true, "glds256x256x32"},    // same with 32-deep slabs: one barrier per 256 MFMAs, 128 KB of LDS
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1540,12 +1547,12 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
-	if (cfg == 11) {   // 256x256: whole tiles only (its epilogue has no bounds checks), one pass over K
-		BLA_REQUIRE(m % 256 == 0 && n % 256 == 0 && k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
-		            "gemm config 11 (%s) needs m, n multiples of 256, k >= 32 and a 16-byte aligned C", c.name);
+	if (cfg == 11 || cfg == 12) {   // 256x256: whole tiles only (its epilogue has no bounds checks), one pass over K
+		BLA_REQUIRE(m % 256 == 0 && n % 256 == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
+		            "gemm config %d (%s) needs m, n multiples of 256, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
 		a.rc_global = 0;   // buffer_load ... lds for every operand: 149.7 vs 146.6 TFLOP/s on NN 4096^3 in this kernel
 		BLA_REQUIRE(!a.bias_row && !a.bias_col && !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !deferred_row_sum, BLA_ERR_INVALID,
-		            "gemm config 11 (%s) takes a plain epilogue (alpha only)", c.name);
+		            "gemm config %d (%s) takes a plain epilogue (alpha only)", cfg, c.name);
 		splits = 1;
 	}
 	if (cfg == 10) {   // persistent variant: one pass over K per tile, slab parity must restart with every tile
@@ -1586,7 +1593,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			unsigned tiles = grid.x, cap = 2u * (unsigned)cus;
 			e = launch_glds<128, 128, 16, 2, 2, 1, 2, true>(a, akc, bkc, dim3(tiles < cap ? tiles : cap, 1, 1), s);
 		} break;
-		default: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;   // 11
+		case 11: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;   // 12
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
