@@ -73,6 +73,25 @@ __global__ void __launch_bounds__(1024) mfma_rate_kernel(int iters, float* sink)
 	float t = c0[0] + c1[0] + c2[0] + c3[0];
 	if (t == 123.456f) sink[0] = t;   // keep the accumulators live
 }
+typedef float mfma_acc4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(1024) mfma_rate_16x16_kernel(int iters, float* sink) {   // the other fp32 shape: v_mfma_f32_16x16x4_f32, 8 passes
+	mfma_acc4_t c0, c1, c2, c3, c4, c5, c6, c7;
+#pragma unroll
+	for (int r = 0; r < 4; r++) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; c4[r] = 0.f; c5[r] = 0.f; c6[r] = 0.f; c7[r] = 0.f; }
+	float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
+	for (int it = 0; it < iters; it++) {   // 16 MFMAs of 2048 FLOP each per trip = the FLOPs of 8 MFMAs 32x32x2
+		asm volatile("v_mfma_f32_16x16x4_f32 %0, %8, %9, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %9, %1\n\tv_mfma_f32_16x16x4_f32 %2, %8, %9, %2\n\t"
+		             "v_mfma_f32_16x16x4_f32 %3, %8, %9, %3\n\tv_mfma_f32_16x16x4_f32 %4, %8, %9, %4\n\tv_mfma_f32_16x16x4_f32 %5, %8, %9, %5\n\t"
+		             "v_mfma_f32_16x16x4_f32 %6, %8, %9, %6\n\tv_mfma_f32_16x16x4_f32 %7, %8, %9, %7\n\t"
+		             "v_mfma_f32_16x16x4_f32 %0, %8, %9, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %9, %1\n\tv_mfma_f32_16x16x4_f32 %2, %8, %9, %2\n\t"
+		             "v_mfma_f32_16x16x4_f32 %3, %8, %9, %3\n\tv_mfma_f32_16x16x4_f32 %4, %8, %9, %4\n\tv_mfma_f32_16x16x4_f32 %5, %8, %9, %5\n\t"
+		             "v_mfma_f32_16x16x4_f32 %6, %8, %9, %6\n\tv_mfma_f32_16x16x4_f32 %7, %8, %9, %7"
+		             : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7) : "v"(a), "v"(b));
+	}
+	asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+	float t = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
+	if (t == 123.456f) sink[0] = t;
+}
 }  // namespace bla
 
 extern "C" {
@@ -291,8 +310,9 @@ bla_status bla_graph_destroy(void* graph) {
 bla_status bla_diag_mfma_rate(void* stream, int blocks, int waves, int iters, float* d_sink) {
 	bla_status st = require_ready();
 	if (st) return st;
-	BLA_REQUIRE(blocks > 0 && waves > 0 && waves <= 16 && iters > 0 && d_sink, BLA_ERR_INVALID, "bad argument");
-	hipLaunchKernelGGL(bla::mfma_rate_kernel, dim3(blocks), dim3(waves * 64), 0, pick_stream(stream), iters, d_sink);
+	BLA_REQUIRE(blocks > 0 && waves != 0 && waves <= 16 && waves >= -16 && iters > 0 && d_sink, BLA_ERR_INVALID, "bad argument");
+	if (waves < 0) hipLaunchKernelGGL(bla::mfma_rate_16x16_kernel, dim3(blocks), dim3(-waves * 64), 0, pick_stream(stream), iters, d_sink);   // negative: the 16x16x4 shape
+	else hipLaunchKernelGGL(bla::mfma_rate_kernel, dim3(blocks), dim3(waves * 64), 0, pick_stream(stream), iters, d_sink);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
