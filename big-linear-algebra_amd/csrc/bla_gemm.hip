@@ -1261,6 +1261,7 @@ static const Config kConfigs[] = {
 	{128, 128, 16, 256, true, "glds128x128x16p"},   // persistent: 2 workgroups per CU walk the tile list, slab stream continuous across tiles
 	{256, 256, 16, 256, true, "glds256x256x16"},    // one workgroup per CU, each wave a 128x128 sub-tile (256 accumulator registers)
 	{256, 256, 32, 256, true, "glds256x256x32"},    // same with 32-deep slabs: one barrier per 256 MFMAs, 128 KB of LDS
+	{128, 512, 16, 256, true, "glds128x512x16"},    // the same pipeline for products with 128 rows: four waves side by side, each 128x128
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1467,19 +1468,20 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
 			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
 			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
-			const int cand[4] = {3, 7, 4, 11};
-			const double eff[4] = {1.0, 0.95, 0.87, 1.03};
+			const int cand[5] = {3, 7, 4, 11, 13};
+			const double eff[5] = {1.0, 0.95, 0.87, 1.03, 1.03};
 			// 256x256 (config 11): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C only
-			const bool big_ok = m % 256 == 0 && n % 256 == 0 && k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
+			const bool big_ok = k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
 			                    !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !a.row_sum_a;
 			double best = 0;
-			for (int i = 0; i < (big_ok ? 4 : 3); i++) {
+			for (int i = 0; i < 5; i++) {
 				const Config& cc = kConfigs[cand[i]];
+				if (i >= 3 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;   // 256x256 / 128x512: whole tiles, plain epilogue
 				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
 				long rounds = (t + cus - 1) / cus;
 				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
-				if (t < 2L * cus && cand[i] != 11) cost /= 0.88;
-				if (cand[i] == 11 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
+				if (t < 2L * cus && i < 3) cost /= 0.88;
+				if (i >= 3 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
 				if (i == 0 || cost < best) { best = cost; cfg = cand[i]; }
 			}
 		}
@@ -1547,9 +1549,9 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
-	if (cfg == 11 || cfg == 12) {   // 256x256: whole tiles only (its epilogue has no bounds checks), one pass over K
-		BLA_REQUIRE(m % 256 == 0 && n % 256 == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
-		            "gemm config %d (%s) needs m, n multiples of 256, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
+	if (cfg >= 11 && cfg <= 13) {   // one-workgroup-per-CU tiles: whole tiles only (the epilogue has no bounds checks), one pass over K
+		BLA_REQUIRE(m % c.bm == 0 && n % c.bn == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
+		            "gemm config %d (%s) needs m, n multiples of the tile, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
 		a.rc_global = 0;   // buffer_load ... lds for every operand: 149.7 vs 146.6 TFLOP/s on NN 4096^3 in this kernel
 		BLA_REQUIRE(!a.bias_row && !a.bias_col && !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !deferred_row_sum, BLA_ERR_INVALID,
 		            "gemm config %d (%s) takes a plain epilogue (alpha only)", cfg, c.name);
@@ -1594,7 +1596,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			e = launch_glds<128, 128, 16, 2, 2, 1, 2, true>(a, akc, bkc, dim3(tiles < cap ? tiles : cap, 1, 1), s);
 		} break;
 		case 11: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;   // 12
+		case 12: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;   // 13
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
