@@ -175,7 +175,7 @@ def test_argument_errors(dev):
     assert (c.numpy() == 0).all()
 
 
-@pytest.mark.parametrize("n", [1024, 4096])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])   # every size of BASELINE configs[1]
 def test_large_square_sampled_rows(dev, ora, n):
     """BASELINE config 2 sizes: oracle on a sample of output rows (full oracle would take minutes),
     plus exactness properties that hold at any size: A @ I == A bit-for-bit and linearity in alpha."""
