@@ -277,7 +277,7 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && BN == 128 && BK == 16 && WM * WN == 4),
 	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image, mode 4 gathers A and takes a K-contiguous B");
@@ -582,7 +582,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//  * every LDS read and DMA instruction is dealt out BETWEEN MFMAs (one read unit per 8 or 2 MFMAs, one DMA per 2) instead of
 	//    standing in a clump behind the barrier.  All LDS reads of a phase come before its first DMA: hipcc waits for vmcnt(0) in
 	//    front of any LDS read that follows an LDS-DMA.
-	constexpr bool HALFSLAB = TM == 4 && TN == 4 && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;   // BK = 16 or 32
+	// the half-slab interleaved pipeline: always for 4x4 blocks per wave (256x256, 128x512), on request (HS) for 2x2 (128x128)
+	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && TM == 2 && TN == 2)) && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;
 	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -665,20 +666,22 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			// and reloads them one by one behind each branch); one block at a time
 			if constexpr (HALFSLAB) {
 				// block (im, in), register r of lane (l31, h): row index inside the block i = (r&3) + 8*(r>>2) + 4h, column index l31.
-				// K-contiguous operand: block b owns rows / columns w0 + 32 b + index; row-contiguous: w0 + 4 index + b.
+				// K-contiguous operand: block b owns rows / columns w0 + 32 b + index; row-contiguous: w0 + T*index + b (T blocks interleaved).
 #pragma unroll
 				for (int im = 0; im < TM; im++)
 #pragma unroll
 					for (int r = 0; r < 16; r++) {
 						const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-						const int row = m0 + wm0 + (AKC ? im * 32 + i : 4 * i + im);
+						const int row = m0 + wm0 + (AKC ? im * 32 + i : TM * i + im);
 						float* cp = p.C + (size_t)row * p.ldc + n0 + wn0;
 						if (BKC) {
 #pragma unroll
 							for (int in = 0; in < TN; in++) cp[in * 32 + l31] = p.alpha * acc[im][in][r];
-						} else {   // four consecutive columns per lane
+						} else if (TN == 4) {   // four consecutive columns per lane
 							*reinterpret_cast<float4*>(cp + 4 * l31) =
-								make_float4(p.alpha * acc[im][0][r], p.alpha * acc[im][1][r], p.alpha * acc[im][2][r], p.alpha * acc[im][3][r]);
+								make_float4(p.alpha * acc[im][0][r], p.alpha * acc[im][1][r], p.alpha * acc[im][TN > 2 ? 2 : 0][r], p.alpha * acc[im][TN > 3 ? 3 : 0][r]);
+						} else {
+							*reinterpret_cast<float2*>(cp + 2 * l31) = make_float2(p.alpha * acc[im][0][r], p.alpha * acc[im][1][r]);
 						}
 					}
 				return;
@@ -730,44 +733,55 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		// slab would start by waiting for a fetch issued half a microsecond earlier.  The asm reads are invisible to that rule; their
 		// results are tied to an explicit s_waitcnt lgkmcnt(0) ("land") in front of their first MFMA.
 		typedef float v4f __attribute__((ext_vector_type(4)));
-		typedef float v2f __attribute__((ext_vector_type(2)));
+		typedef float vra __attribute__((ext_vector_type(TM)));   // row-contiguous A: one element per block
+		typedef float vrb __attribute__((ext_vector_type(TN)));
 		typedef __attribute__((address_space(3))) float* lds_f;
 		const unsigned lds0 = (unsigned)(size_t)(lds_f)lds;
 		constexpr unsigned BUF_BYTES = (A_SZ + B_SZ) * 4;
-		// K-contiguous operand: block x of k-half kk = 16 bytes at row w0 + x*32 + l31, chunk kk*2 + h (x only adds a multiple of 2048 bytes).
-		// Row-contiguous operand: its four blocks do not own 32 consecutive rows each but the rows w0 + 4*lane + block -- then ONE 16-byte
-		// read at (k, w0 + 4*l31) delivers a lane's element of all four blocks for that k (instead of four dwords), and in the output a lane
-		// holds four consecutive columns (16-byte stores).  Which rows / columns a block owns is a free choice: only the epilogue's index map changes.
+		// K-contiguous operand: block x of k-part kk = 16 bytes at row w0 + x*32 + l31, chunk kk*2 + h (x only adds a multiple of 32 rows).
+		// Row-contiguous operand: its T blocks do not own 32 consecutive rows each but the rows w0 + T*lane + block -- then ONE read of
+		// 4T bytes at (k, w0 + T*l31) delivers a lane's element of all T blocks for that k (instead of T dwords), and in the output a lane
+		// holds T consecutive columns (wide stores).  Which rows / columns a block owns is a free choice: only the epilogue's index map changes.
 		unsigned a_ad[KK], b_ad[KK];
 #pragma unroll
 		for (int kk = 0; kk < KK; kk++) {
-			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + 4 * l31) * 4;
-			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + 4 * l31)) * 4;
+			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + TM * l31) * 4;
+			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + TN * l31)) * 4;
 		}
 		struct Frag {
-			v4f a[4], b[4];   // K-contiguous: [block], elements = k-offset j; row-contiguous: [k-offset j], elements = block
+			v4f ka[TM], kb[TN];   // K-contiguous: [block], elements = k-offset j
+			vra ra[4]; vrb rb[4]; // row-contiguous: [k-offset j], elements = block
 		};
 		Frag P, Q;
-		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.a[im][j] : f.a[j][im]; };
-		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.b[in][j] : f.b[j][in]; };
-		auto mf1 = [&](const Frag& f, int idx) {   // idx-th of the 64 MFMAs of a k-half: j-major, then im, in
-			const int j = idx / 16, im = (idx % 16) / 4, in = idx % 4;
+		constexpr int UA = AKC ? TM : 4, UB = BKC ? TN : 4, NU = UA + UB;   // fragment-read units per k-part
+		constexpr int NM = 4 * TM * TN;                                       // MFMAs per k-part
+		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.ka[im][j] : f.ra[j][im]; };
+		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.kb[in][j] : f.rb[j][in]; };
+		auto mf1 = [&](const Frag& f, int idx) {   // idx-th MFMA of a k-part: j-major, then im, in
+			const int j = idx / (TM * TN), im = (idx % (TM * TN)) / TN, in = idx % TN;
 			acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(f, im, j), opb(f, in, j), acc[im][in], 0, 0, 0);
 		};
-		auto read_unit = [&](unsigned buf, int kk, int u, Frag& f) {   // units 0..3: A side, 4..7: B side
-			const int x = u & 3;
-			if (u < 4) {
+		auto read_unit = [&](unsigned buf, int kk, int u, Frag& f) {   // units 0..UA-1: A side, then B side
+			if (u < UA) {
+				const int x = u;
 				const unsigned ad = buf + a_ad[kk];
-				if (AKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[x]) : "v"(ad), "n"(x * 32 * BK * 4));
-				else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[x]) : "v"(ad), "n"(x * BM * 4));
+				if (AKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ka[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else if (TM == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
+				else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
 			} else {
+				const int x = u - UA;
 				const unsigned ad = buf + b_ad[kk];
-				if (BKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[x]) : "v"(ad), "n"(x * 32 * BK * 4));
-				else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[x]) : "v"(ad), "n"(x * BN * 4));
+				if (BKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.kb[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else if (TN == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.rb[x]) : "v"(ad), "n"(x * BN * 4));
+				else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.rb[x]) : "v"(ad), "n"(x * BN * 4));
 			}
 		};
-		auto land = [&](Frag& f) {   // every read into f has returned; later uses of f depend on this statement
-			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
+		auto land = [&](Frag& f) {   // every read into f has returned; the empty statements make each register's later uses depend on the wait
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+			for (int x = 0; x < UA; x++) { if (AKC) asm volatile("" : "+v"(f.ka[x])); else asm volatile("" : "+v"(f.ra[x])); }
+#pragma unroll
+			for (int x = 0; x < UB; x++) { if (BKC) asm volatile("" : "+v"(f.kb[x])); else asm volatile("" : "+v"(f.rb[x])); }
 		};
 		// slab t in buffer t&1.  One uniform body for every slab: past the end the fetch cursor stays on the last slab (re-fetched
 		// into a buffer nobody reads again) and the "next" fragments are stale LDS that is never multiplied -- so there is no tail
@@ -781,18 +795,18 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		};
 		auto slab = [&](int t) {
 			const unsigned cur = (t & 1) * BUF_BYTES, nxt = ((t + 1) & 1) * BUF_BYTES;
-			// phases 0 .. KK-2: k-part q from one set while k-part q+1 of this slab is read into the other, one read unit per 8 MFMAs
+			// phases 0 .. KK-2: k-part q from one set while k-part q+1 of this slab is read into the other, the read units spread evenly
 #pragma unroll
 			for (int q = 0; q + 1 < KK; q++) {
 				Frag& use = (q & 1) ? Q : P;
 				Frag& fill = (q & 1) ? P : Q;
 				land(use);
 #pragma unroll
-				for (int u = 0; u < 8; u++) {
+				for (int u = 0; u < NU; u++) {
 					read_unit(cur, q + 1, u, fill);
 					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-					for (int m = 0; m < 8; m++) mf1(use, u * 8 + m);
+					for (int m = u * NM / NU; m < (u + 1) * NM / NU; m++) mf1(use, m);
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
@@ -800,23 +814,27 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			land(Q);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
+			constexpr int PER = 2 * (NU + NDMA) <= NM ? 2 : 1;   // MFMAs after each read unit / DMA instruction
+			static_assert(PER * (NU + NDMA) <= NM, "too many memory instructions for the MFMAs of one k-part");
 #pragma unroll
-			for (int u = 0; u < 8; u++) {     // k-part 0 of slab t+1 -> P, one read unit per 2 MFMAs
+			for (int u = 0; u < NU; u++) {    // k-part 0 of slab t+1 -> P (all LDS reads before the first DMA)
 				read_unit(nxt, 0, u, P);
 				__builtin_amdgcn_sched_barrier(0);
-				mf1(Q, 2 * u); mf1(Q, 2 * u + 1);
+#pragma unroll
+				for (int m = 0; m < PER; m++) mf1(Q, PER * u + m);
 				__builtin_amdgcn_sched_barrier(0);
 			}
 #pragma unroll
-			for (int d = 0; d < NDMA; d++) {  // slab t+2 -> this slab's buffer, one DMA per 2 MFMAs
+			for (int d = 0; d < NDMA; d++) {  // slab t+2 -> this slab's buffer
 				dma_one(t & 1, d);
 				__builtin_amdgcn_sched_barrier(0);
-				mf1(Q, 16 + 2 * d); mf1(Q, 16 + 2 * d + 1);
+#pragma unroll
+				for (int m = 0; m < PER; m++) mf1(Q, PER * (NU + d) + m);
 				__builtin_amdgcn_sched_barrier(0);
 			}
 			{ const bool adv = fetched + 1 < nkt; dma_advance(adv); fetched += adv ? 1 : 0; }
 #pragma unroll
-			for (int m = 16 + 2 * NDMA; m < 64; m++) mf1(Q, m);
+			for (int m = PER * (NU + NDMA); m < NM; m++) mf1(Q, m);
 			__builtin_amdgcn_sched_barrier(0);
 		};
 		if (nkt > 0) {
@@ -825,7 +843,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 #pragma unroll
-			for (int u = 0; u < 8; u++) read_unit(0, 0, u, P);
+			for (int u = 0; u < NU; u++) read_unit(0, 0, u, P);
 			for (int t = 0; t < nkt; t++) slab(t);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetches of the last slab
 		}
@@ -1262,6 +1280,7 @@ static const Config kConfigs[] = {
 	{256, 256, 16, 256, true, "glds256x256x16"},    // one workgroup per CU, each wave a 128x128 sub-tile (256 accumulator registers)
 	{256, 256, 32, 256, true, "glds256x256x32"},    // same with 32-deep slabs: one barrier per 256 MFMAs, 128 KB of LDS
 	{128, 512, 16, 256, true, "glds128x512x16"},    // the same pipeline for products with 128 rows: four waves side by side, each 128x128
+	{128, 128, 16, 256, true, "glds128x128x16h"},   // the same pipeline on the 128x128 tile (whole tiles, plain epilogue)
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1301,13 +1320,13 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode
 #undef BLA_LAUNCH
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bool PERSIST = false>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bool PERSIST = false, bool HS = false>
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 	size_t lds_bytes = NBUF * (BM + BN) * BK * sizeof(float);
 	dim3 block(WM * WN * 64);
 #define BLA_LAUNCH2(AK, BK_, RG)                                                                            \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST, 0, RG>;          \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST, 0, RG, HS>;      \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -1549,7 +1568,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
-	if (cfg >= 11 && cfg <= 13) {   // one-workgroup-per-CU tiles: whole tiles only (the epilogue has no bounds checks), one pass over K
+	if (cfg >= 11 && cfg <= 14) {   // half-slab pipeline: whole tiles only (the epilogue has no bounds checks), one pass over K
 		BLA_REQUIRE(m % c.bm == 0 && n % c.bn == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
 		            "gemm config %d (%s) needs m, n multiples of the tile, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
 		a.rc_global = 0;   // buffer_load ... lds for every operand: 149.7 vs 146.6 TFLOP/s on NN 4096^3 in this kernel
@@ -1597,7 +1616,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		} break;
 		case 11: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 12: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;   // 13
+		case 13: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 128, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 14
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
