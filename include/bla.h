@@ -141,7 +141,12 @@ typedef struct bla_gemm_desc {
 } bla_gemm_desc;
 BLA_API bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q);
 
-/* Tuning/diagnostics: force a tile configuration (-1 = automatic) and split-K factor (0 = automatic). */
+/* Tuning/diagnostics: force a tile configuration (-1 = automatic) and split-K factor (0 = automatic).  Configurations
+ * (csrc/bla_gemm.hip): 0-2 register-staged tiles (any shape); 3/4/5/7 direct-to-LDS 128x128x16, 64x64x16, 128x128x32, 128x64x16
+ * (16-byte aligned operands, k a multiple of the slab depth); 6 wave-split-K 32x32 for latency-bound shapes; 8/9 256x128-class
+ * three-buffer tiles; 10 persistent 128x128; 11/12/13 the one-workgroup-per-CU half-slab kernels 256x256x16, 256x256x32, 128x512x16
+ * and 14 their 128x128 form (whole tiles, plain alpha epilogue only).  A forced configuration that cannot take the call fails with
+ * BLA_ERR_INVALID; the automatic choice never does. */
 BLA_API bla_status bla_gemm_set_config(int config, int split_k);
 /* Name of the kernel variant the last bla_gemm_f32 call launched (for profiles/). */
 BLA_API const char* bla_gemm_last_kernel(void);
