@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//    standing in a clump behind the barrier.  All LDS reads of a phase come before its first DMA: hipcc waits for vmcnt(0) in
 	//    front of any LDS read that follows an LDS-DMA.
 	// the half-slab interleaved pipeline: always for 4x4 blocks per wave (256x256, 128x512), on request (HS) for 2x2 (128x128)
-	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && TM == 2 && TN == 2)) && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;
+	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && (TM == 2 || TM == 4) && (TN == 2 || TN == 4))) && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;
 	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1281,6 +1281,7 @@ static const Config kConfigs[] = {
 	{256, 256, 32, 256, true, "glds256x256x32"},    // same with 32-deep slabs: one barrier per 256 MFMAs, 128 KB of LDS
 	{128, 512, 16, 256, true, "glds128x512x16"},    // the same pipeline for products with 128 rows: four waves side by side, each 128x128
 	{128, 128, 16, 256, true, "glds128x128x16h"},   // the same pipeline on the 128x128 tile (whole tiles, plain epilogue)
+	{128, 256, 16, 256, true, "glds128x256x16h"},   // ... and on 128x256 (waves 2x2, each 64x128): +8 % on 128 x 1152 x 65536, behind elsewhere
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1568,7 +1569,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
-	if (cfg >= 11 && cfg <= 14) {   // half-slab pipeline: whole tiles only (the epilogue has no bounds checks), one pass over K
+	if (cfg >= 11 && cfg <= 15) {   // half-slab pipeline: whole tiles only (the epilogue has no bounds checks), one pass over K
 		BLA_REQUIRE(m % c.bm == 0 && n % c.bn == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
 		            "gemm config %d (%s) needs m, n multiples of the tile, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
 		a.rc_global = 0;   // buffer_load ... lds for every operand: 149.7 vs 146.6 TFLOP/s on NN 4096^3 in this kernel
@@ -1617,7 +1618,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		case 11: e = launch_glds<256, 256, 16, 2, 2>(a, akc, bkc, grid, s); break;
 		case 12: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;
 		case 13: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 128, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 14
+		case 14: e = launch_glds<128, 128, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<128, 256, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 15
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};
