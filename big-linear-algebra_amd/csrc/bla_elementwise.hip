@@ -123,8 +123,10 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 // 16-byte global loads and stores on both sides (needs rows % 4 == 0, cols % 4 == 0, 16-byte aligned bases)
 __global__ void __launch_bounds__(256) transpose_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
 	__shared__ float tile[64][65];
-	int tiles_c = (cols + 63) / 64;
-	int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+	int tiles_c = (cols + 63) / 64, tiles_r = (rows + 63) / 64;
+	// diagonal walk: consecutive workgroups move down AND right, so neither their reads nor their writes line up on one column of
+	// tiles (at a power-of-two pitch a column of tiles sits on a few HBM channels)
+	int tr = blockIdx.x % tiles_r, tc = (blockIdx.x / tiles_r + tr) % tiles_c;
 	int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 chunks of 4 floats x 16 rows per pass
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
