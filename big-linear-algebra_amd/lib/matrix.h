@@ -25,25 +25,37 @@ typedef struct Matrix {
 	matrix_float_t* data;
 } Matrix;
 
-struct Matrix* make_matrix(int rows, int cols, matrix_float_t* data);
-struct Matrix* clone_matrix(struct Matrix m);
-void free_matrix_data(struct Matrix* m);
-void free_matrix(struct Matrix* m);
-struct Matrix* matrix_multiply(struct Matrix a, struct Matrix b);
-void matrix_scale(struct Matrix* m, matrix_float_t f);
-void matrix_add(struct Matrix* a, struct Matrix* b);
-void print_matrix(struct Matrix m);
-void print_matrix_dim(struct Matrix m);
-void matrix_multiply_elementwise(struct Matrix* a, struct Matrix* b);
-void matrix_transpose(struct Matrix* m);
-struct Matrix* matrix_row_sum(struct Matrix m);
-struct Matrix* matrix_col_sum(struct Matrix m);
-matrix_float_t frobenius_norm(struct Matrix m);
-matrix_float_t max_value(struct Matrix m);
-void matrix_z_score_normalize(Matrix* m);
-void matrix_add_tile_columns(struct Matrix* a, struct Matrix* b);
-void matrix_add_tile_rows(struct Matrix* a, struct Matrix* b);
+/* ---- lifecycle (lib/matrix.c:6-32): plain malloc / free, released by the caller ---------------------------------------- */
+struct Matrix* make_matrix(int rows, int cols, matrix_float_t* values);   /* adopts `values` (no copy) */
+struct Matrix* clone_matrix(struct Matrix src);                           /* deep copy */
+void free_matrix(struct Matrix* mat);                                     /* data, then the struct */
+void free_matrix_data(struct Matrix* mat);                                /* data only */
 
-void matrix_multiply_inplace(Matrix* a, Matrix* b, Matrix* c);
+/* ---- products (lib/matrix.c:35-57): fp32 MFMA GEMM on the device ----------------------------------------------------- */
+/* out = lhs . rhs into a new matrix; on a shape mismatch prints the reference's message and exit(1)s, like :36-39 */
+struct Matrix* matrix_multiply(struct Matrix lhs, struct Matrix rhs);
+/* out[j * rhs->cols + i] = sum_k lhs[j][k] rhs[k][i]; no checks, `out`'s own dimensions are ignored (as in :47-57) */
+void matrix_multiply_inplace(Matrix* lhs, Matrix* rhs, Matrix* out);
+
+/* ---- elementwise, in place (lib/matrix.c:59-69,95-103) ---------------------------------------------------------------- */
+void matrix_scale(struct Matrix* mat, matrix_float_t factor);
+void matrix_add(struct Matrix* acc, struct Matrix* addend);                       /* acc += addend over acc's size, unchecked */
+void matrix_multiply_elementwise(struct Matrix* acc, struct Matrix* other);       /* Hadamard; exit(1) on a shape mismatch (:96-99) */
+
+/* ---- broadcasts (lib/matrix.c:189-205) -------------------------------------------------------------------------------- */
+void matrix_add_tile_columns(struct Matrix* acc, struct Matrix* tile);   /* acc[r][c] += tile[r][c % tile->cols] (a bias column when tile is n x 1) */
+void matrix_add_tile_rows(struct Matrix* acc, struct Matrix* tile);      /* acc[r][c] += tile[0][c] */
+
+/* ---- layout and reductions (lib/matrix.c:105-185) ---------------------------------------------------------------------- */
+void matrix_transpose(struct Matrix* mat);                  /* in place: swaps rows / cols and rewrites the data */
+struct Matrix* matrix_row_sum(struct Matrix mat);           /* 1 x cols: sums down every column */
+struct Matrix* matrix_col_sum(struct Matrix mat);           /* rows x 1 AS WRITTEN at :138-148 (flat windows; see matrix.c and SURVEY Q2) */
+matrix_float_t frobenius_norm(struct Matrix mat);
+matrix_float_t max_value(struct Matrix mat);
+void matrix_z_score_normalize(Matrix* mat);                 /* (x - mean) / sqrtf(E[x^2] - mean^2) */
+
+/* ---- printing (lib/matrix.c:71-93), host ------------------------------------------------------------------------------- */
+void print_matrix(struct Matrix mat);
+void print_matrix_dim(struct Matrix mat);
 
 #endif

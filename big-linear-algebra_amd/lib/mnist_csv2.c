@@ -9,46 +9,50 @@
 
 enum { ROW = 785, PIXELS = 784 };
 
-void mnist_csv_init(MnistCSV* csv) {                     /* reference lib/mnist_csv2.c:13-34 */
-	int values = 0;
-	float* flat = read_csv_contents_file(csv->file, &values);   /* closes csv->file */
+void mnist_csv_init(MnistCSV* store) {                   /* reference lib/mnist_csv2.c:13-34 */
+	int count = 0;
+	float* flat = read_csv_contents_file(store->file, &count);   /* closes store->file */
 	printf("MNIST CSV file contents read!\n");
-	int n = values / ROW;
-	csv->num_examples = n;
-	csv->X = malloc((size_t)n * PIXELS * sizeof(float));
-	csv->y = malloc((size_t)n * sizeof(float));
-	csv->sampled = calloc(n > 0 ? n : 1, 1);
-	csv->num_sampled = 0;
-	for (int e = 0; e < n; e++) {
-		const float* row = flat + (size_t)e * ROW;
-		csv->y[e] = row[0];
-		for (int px = 0; px < PIXELS; px++) csv->X[(size_t)px * n + e] = row[px + 1];
+	const int examples = count / ROW;
+	store->num_examples = examples;
+	store->num_sampled = 0;
+	store->sampled = calloc(examples > 0 ? examples : 1, 1);
+	store->y = malloc((size_t)examples * sizeof(float));
+	store->X = malloc((size_t)examples * PIXELS * sizeof(float));
+	/* file order is example-major (label, then its pixels); the store is feature-major */
+	const float* cursor = flat;
+	for (int e = 0; e < examples; e++, cursor += ROW) {
+		store->y[e] = cursor[0];
+		float* column = store->X + e;
+		for (int px = 0; px < PIXELS; px++, column += examples) *column = cursor[1 + px];
 	}
 	free(flat);
 }
 
-MnistExample get_random_data_replace(MnistCSV* csv) {    /* reference lib/mnist_csv2.c:36-39 */
-	int n = (int)floor((float)csv->num_examples * (float)rand() / (float)RAND_MAX);
-	MnistExample ex = {csv->X + n, csv->y[n], csv->num_examples};
-	return ex;
+/* both samplers scale rand() by 1 / RAND_MAX in float and floor, exactly as the reference does (so RAND_MAX itself maps one past the range --
+ * a quirk kept for identical streams) */
+static int draw_below(int bound) { return (int)floor((float)bound * (float)rand() / (float)RAND_MAX); }
+
+MnistExample get_random_data_replace(MnistCSV* store) {  /* reference lib/mnist_csv2.c:36-39 */
+	const int pick = draw_below(store->num_examples);
+	MnistExample out = {store->X + pick, store->y[pick], store->num_examples};
+	return out;
 }
 
-MnistExample get_random_data_take(MnistCSV* csv) {       /* reference lib/mnist_csv2.c:41-62 */
-	if (csv->num_sampled == csv->num_examples) {
-		csv->num_sampled = 0;
-		memset(csv->sampled, 0, csv->num_examples);
+MnistExample get_random_data_take(MnistCSV* store) {     /* reference lib/mnist_csv2.c:41-62 */
+	if (store->num_sampled == store->num_examples) {        /* everything taken: start over */
+		memset(store->sampled, 0, store->num_examples);
+		store->num_sampled = 0;
 	}
-	/* the n-th still-unsampled example, counted the way the reference counts it */
-	int n = (int)floor((float)(csv->num_examples - csv->num_sampled) * (float)rand() / (float)RAND_MAX);
-	int i = 0;
-	while (i < csv->num_examples && n > 0) {
-		if (!csv->sampled[i]) n--;
-		i++;
-	}
-	csv->sampled[i] = 1;
-	csv->num_sampled++;
-	MnistExample ex = {csv->X + i, csv->y[i], csv->num_examples};
-	return ex;
+	/* skip `skip` still-untaken examples, counted the way the reference counts them, and take where the walk stops */
+	int skip = draw_below(store->num_examples - store->num_sampled);
+	int at = 0;
+	for (; at < store->num_examples && skip > 0; at++)
+		if (!store->sampled[at]) skip--;
+	store->sampled[at] = 1;
+	store->num_sampled++;
+	MnistExample out = {store->X + at, store->y[at], store->num_examples};
+	return out;
 }
 
 void visualize_digit_data(MnistExample ex) {              /* reference lib/mnist_csv2.c:64-80 */

@@ -20,9 +20,14 @@ typedef struct MnistExample {
 	int num_examples;
 } MnistExample;
 
-void mnist_csv_init(MnistCSV* csv);
-MnistExample get_random_data_replace(MnistCSV* csv);   /* uniform, with replacement */
-MnistExample get_random_data_take(MnistCSV* csv);      /* uniform, without replacement (restarts when exhausted) */
-void visualize_digit_data(MnistExample ex);
+/* reads the whole file behind store->file (label + 784 pixels per row, every value comma-terminated) into the feature-major arrays
+ * and closes it; prints the reference's progress line (lib/mnist_csv2.c:13-34) */
+void mnist_csv_init(MnistCSV* store);
+/* one example drawn uniformly WITH replacement from libc rand() (:36-39) */
+MnistExample get_random_data_replace(MnistCSV* store);
+/* one example drawn from those not yet taken; starts over when all were taken (:41-62) */
+MnistExample get_random_data_take(MnistCSV* store);
+/* 28 x 28 ASCII rendering (' ' < 80 <= ':' < 150 <= '#') between two rules (:64-80) */
+void visualize_digit_data(MnistExample example);
 
 #endif
