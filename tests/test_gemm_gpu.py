@@ -372,3 +372,11 @@ def test_automatic_dispatch_fuzz(dev):
         got = dC.numpy()
         assert np.all(np.abs(got[:, :n] - 0.25 * (opA @ opB)) <= 1e-5 * (np.abs(opA) @ np.abs(opB))), (ta, tb)
         assert not got[:, n:].any()
+    # ... and the 128x512 tile: 128 rows, exactly one tile per CU
+    m, n, k = 128, 512 * 256, 48
+    A = uniform(70, (m, k), dtype=np.float32); B = uniform(71, (k, n), dtype=np.float32)
+    dA, dB, dC = dev.to_device(A), dev.to_device(B), dev.zeros((m, n))
+    dev.gemm(dA, dB, dC)
+    assert "glds128x512x16" in dev.lib().bla_gemm_last_kernel().decode()
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    assert np.all(np.abs(dC.numpy() - ref) <= 1e-5 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)))
