@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostics (never part of the product): builds libbla_hip with -DBLA_WSK_DIAG into gpurun_out/diag/, runs one
-latency-bound GEMM and prints where workgroup 0 / wave 0 spends its cycles (s_memtime stamps, 100 MHz... shader clock)."""
+latency-bound GEMM and prints where workgroup 0 / wave 0 spends its cycles (s_memtime stamps).  The kernel currently carries three
+stamps -- start, K loop done, after the barrier in front of the fold; per-chunk stamps (slots 1..19) print only if a build adds them."""
 import ctypes as C, glob, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
