@@ -45,6 +45,7 @@ struct GemmArgs {
 #endif
 	unsigned* counters;            // wsk kernels with splits > 1: one arrival counter per output tile (zero between launches)
 	float* row_sum_a;              // fused bias gradient: row_sum_a[r] = sum_k op(A)[r][k]   (wsk kernels, A K-contiguous)
+	float rs_alpha, rs_beta;       // ... stored as rs_beta * old + rs_alpha * sum (1, 0 = plain)
 	const float* softmax_y; float softmax_scale; float* softmax_grad;   // fused column softmax + (p - y)*scale (wsk kernels, M <= 32)
 	// implicit-GEMM convolution over a batch of images (gather variants of the direct-to-LDS kernel only): the B operand is
 	// never stored, element (k, n) is img[g_off(k) + g_off(n)] when (y(k) + y(n), x(k) + x(n)) lies inside the H x W image, else 0.
@@ -1161,7 +1162,7 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 		float t = 0.f;
 #pragma unroll
 		for (int w = 0; w < NW; w++) t += red_rs[w][tid] + red_rs[w][tid + 32];
-		p.row_sum_a[m0 + tid] = t;
+		p.row_sum_a[m0 + tid] = p.rs_beta != 0.f ? p.rs_beta * p.row_sum_a[m0 + tid] + p.rs_alpha * t : p.rs_alpha * t;
 	}
 	if (p.splits > 1) {
 		// K is also cut over by (few tiles, long K: otherwise most CUs idle).  Each workgroup publishes its partial
@@ -1457,6 +1458,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 	a.pre_act = ep ? ep->pre_act : nullptr; a.ld_pre = ep ? ep->ld_pre : 0; a.act = ep ? ep->act : BLA_ACT_NONE;
 	a.relu_mask = ep ? ep->relu_mask : nullptr; a.ld_mask = ep ? ep->ld_mask : 0;
 	a.row_sum_a = ep ? ep->row_sum_a : nullptr;
+	a.rs_alpha = ep ? ep->row_sum_alpha : 0.f; a.rs_beta = ep ? ep->row_sum_beta : 0.f;
+	if (a.rs_alpha == 0.f && a.rs_beta == 0.f) a.rs_alpha = 1.f;
 	{   // row-contiguous operand pitches that are powers of two up to 16 KiB: global_load_lds measured ahead (see the kernel)
 		auto pow2_small = [](int ld) { return ld > 0 && (ld & (ld - 1)) == 0 && ld <= 4096; };
 		a.rc_global = (transa ? pow2_small(lda) : true) && (!transb ? pow2_small(ldb) : true);
@@ -1548,6 +1551,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 	}
 	BLA_REQUIRE(!a.softmax_grad || cfg == 6, BLA_ERR_INVALID, "fused softmax is only available on the wave-split-K config (6)");
 	float* deferred_row_sum = nullptr;   // tiled kernels do not fuse the row sum: run it as a separate pass below
+	BLA_REQUIRE(cfg == 6 || !a.row_sum_a || (a.rs_alpha == 1.f && a.rs_beta == 0.f), BLA_ERR_INVALID, "a scaled / accumulated row sum is only available on the wave-split-K config (6)");
 	if (cfg != 6 && a.row_sum_a) { deferred_row_sum = a.row_sum_a; a.row_sum_a = nullptr; }
 	if (kConfigs[cfg].glds && !(vec_ok && k > 0 && k % kConfigs[cfg].bk == 0)) {
 		set_error("gemm config %d (%s) needs 16-byte aligned operands, contiguous extents %% 4 == 0 and k %% %d == 0", cfg,
@@ -1662,6 +1666,10 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 		hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<true, true, false, false>), dim3((unsigned)(tp + tq)), dim3(256), 0, s, pp.a, pq.a, tp);
 		e = hipGetLastError();
 		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_nt+tn_%d+%d", tp, tq);
+	} else if (pp.valid && pq.valid && pp.akc && pp.bkc && pq.akc && pq.bkc && !pp.a.softmax_grad && !pq.a.softmax_grad) {   // NT beside NT (two weight-gradient products)
+		hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<true, true, true, true>), dim3((unsigned)(tp + tq)), dim3(256), 0, s, pp.a, pq.a, tp);
+		e = hipGetLastError();
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_nt+nt_%d+%d", tp, tq);
 	} else {
 		if (pp.valid) e = launch_wsk(pp.a, pp.akc, pp.bkc, true, true, dim3((unsigned)tp, 1), s);
 		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);

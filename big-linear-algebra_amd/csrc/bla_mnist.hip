@@ -230,6 +230,56 @@ bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const float* 
 	return bla_mnist_nn_apply(nn, stream, lr);
 }
 
+/* Forward + backward + update with the update folded into the weight-gradient products: W_l += lr * (dZ_l . A_{l-1}^T) through the
+ * products' alpha / beta (C = W_l), b_l += lr * rowsum(dZ_l) through the scaled row sum -- no gradient bucket, no axpy launch, and the
+ * order changes so that no product updates a matrix another product of the same launch still reads:
+ *     forward x 3;  dZ2 (reads W3);  {W3, b3 update | dZ1 (reads W2)};  {W2, b2 update | W1, b1 update}
+ * 6 launches instead of 7.  Rounding differs from "scale the gradient, then add" (:296-315) by one fused multiply-add per weight.
+ * Only for layer shapes whose every product runs on the wave-split-K kernel (the scaled row sum lives there) and true row sums. */
+static bool can_fuse_update(const bla_mnist_nn* nn, int colsum_mode) {
+	auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
+	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
+	return colsum_mode == BLA_COLSUM_INTENDED && B <= 1280 && n0 <= 1280 && n1 <= 1280 && n2 <= 1280 && n3 <= 32 && t32(n1, B) <= 512 && t32(n2, B) <= 512 &&
+	       t32(n3, n2) <= 512 && t32(n2, n1) <= 512 && t32(n1, n0) <= 512;
+}
+
+static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr) {
+	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
+	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
+	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
+	const float* x = nn->x_raw; const float* y = nn->y;
+	const float xs = 1 / 255.0F;
+	bla_status st;
+	bla_gemm_epilogue ep = {};
+	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
+	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, x, B, nn->a1, B, &ep); if (st) return st;
+	ep.alpha = 1.f; ep.bias_row = b2; ep.pre_act = nn->z2;
+	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;
+	ep.bias_row = b3; ep.pre_act = nn->z3; ep.act = BLA_ACT_NONE;
+	ep.softmax_y = y; ep.softmax_scale = (float)(1 / (double)n0); ep.softmax_grad = nn->dz3;
+	st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
+	bla_gemm_epilogue em2 = {};
+	em2.alpha = 1.f; em2.relu_mask = nn->z2; em2.ld_mask = B;
+	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st;        // dZ2: last reader of W3
+	bla_gemm_epilogue u3 = {}, em1 = {};
+	u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
+	em1.alpha = 1.f; em1.relu_mask = nn->z1; em1.ld_mask = B;
+	{
+		bla_gemm_desc up = {0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, W3, n2, &u3};                             // W3 += lr dZ3 A2^T, b3 += lr rowsum(dZ3)
+		bla_gemm_desc dz = {1, 0, n1, B, n2, W2, n1, nn->dz2, B, nn->dz1, B, &em1};                           // dZ1: last reader of W2
+		st = bla_gemm_pair_f32(s, &up, &dz); if (st) return st;
+	}
+	bla_gemm_epilogue u2 = {}, u1 = {};
+	u2.alpha = lr; u2.beta = 1.f; u2.row_sum_a = b2; u2.row_sum_alpha = lr; u2.row_sum_beta = 1.f;
+	u1.alpha = lr * xs; u1.beta = 1.f; u1.row_sum_a = b1; u1.row_sum_alpha = lr; u1.row_sum_beta = 1.f;
+	{
+		bla_gemm_desc p2 = {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, W2, n1, &u2};
+		bla_gemm_desc p1 = {0, 1, n1, n0, B, nn->dz1, B, x, B, W1, n0, &u1};
+		st = bla_gemm_pair_f32(s, &p2, &p1); if (st) return st;
+	}
+	return BLA_OK;
+}
+
 /* Capture one whole step (resident input/label buffers -> updated parameters) into a hipGraph and replay it:
  * the step is ~25 launches of a few microseconds each, i.e. launch-bound when issued one by one.
  * with_update = 0 captures forward+backward only (data-parallel: the all-reduce sits between the two halves). */
@@ -242,8 +292,11 @@ bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float lr, int
 		if (nn->graph_ready) { (void)hipGraphExecDestroy(nn->graph_exec); (void)hipGraphDestroy(nn->graph); nn->graph_ready = false; }
 		BLA_HIP(hipStreamSynchronize(s));
 		BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-		st = bla_mnist_nn_forward_backward(nn, s, nullptr, nullptr, colsum_mode);
-		if (!st && with_update) st = bla_mnist_nn_apply(nn, s, lr);
+		if (with_update && can_fuse_update(nn, colsum_mode)) st = fused_update_step(nn, s, lr);
+		else {
+			st = bla_mnist_nn_forward_backward(nn, s, nullptr, nullptr, colsum_mode);
+			if (!st && with_update) st = bla_mnist_nn_apply(nn, s, lr);
+		}
 		hipError_t e = hipStreamEndCapture(s, &nn->graph);
 		if (st) { if (e == hipSuccess) (void)hipGraphDestroy(nn->graph); return st; }
 		if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");

@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
     _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("bias_row", C.c_void_p), ("bias_col", C.c_void_p),
                 ("pre_act", C.c_void_p), ("ld_pre", C.c_int), ("act", C.c_int), ("relu_mask", C.c_void_p),
                 ("ld_mask", C.c_int), ("row_sum_a", C.c_void_p), ("softmax_y", C.c_void_p), ("softmax_scale", C.c_float),
-                ("softmax_grad", C.c_void_p)]
+                ("softmax_grad", C.c_void_p), ("row_sum_alpha", C.c_float), ("row_sum_beta", C.c_float)]
 
 
 class GemmDesc(C.Structure):
@@ -227,7 +227,7 @@ def gemm_pair(p, q, stream=None):
 
 def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None, bias_col=None, pre_act=None,
          act=ACT_NONE, relu_mask=None, stream=None, m=None, n=None, k=None, lda=None, ldb=None, ldc=None,
-         row_sum_a=None, softmax_y=None, softmax_scale=0.0, softmax_grad=None):
+         row_sum_a=None, softmax_y=None, softmax_scale=0.0, softmax_grad=None, row_sum_alpha=0.0, row_sum_beta=0.0):
     """C = epilogue(alpha * op(A) op(B)) on device arrays; shapes default to the arrays' own."""
     if m is None:
         m = a.shape[1] if transa else a.shape[0]
@@ -240,7 +240,7 @@ def gemm(a, b, c, transa=False, transb=False, alpha=1.0, beta=0.0, bias_row=None
         raise BlaError(2, f"inner dimensions differ: {k} vs {kb}")
     ep = Epilogue(alpha, beta, _ptr(bias_row), _ptr(bias_col), _ptr(pre_act), pre_act.ld if pre_act is not None else 0,
                   act, _ptr(relu_mask), relu_mask.ld if relu_mask is not None else 0, _ptr(row_sum_a), _ptr(softmax_y),
-                  softmax_scale, _ptr(softmax_grad))
+                  softmax_scale, _ptr(softmax_grad), row_sum_alpha, row_sum_beta)
     check(lib().bla_gemm_f32(stream, int(transa), int(transb), m, n, k, _ptr(a), lda or a.ld, _ptr(b), ldb or b.ld,
                              _ptr(c), ldc or c.ld, C.byref(ep)))
     return c

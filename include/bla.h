@@ -124,6 +124,9 @@ typedef struct bla_gemm_epilogue {
 	const float* softmax_y;
 	float softmax_scale;
 	float* softmax_grad;
+	/* row_sum_a[r] = row_sum_beta * row_sum_a[r] + row_sum_alpha * sum_k A[r][k]; both 0 (a zero-initialised struct) = plain store of the
+	 * sum.  With alpha = learn rate, beta = 1 the bias update b += lr * db rides along the weight-gradient product (latency-bound kernels only). */
+	float row_sum_alpha, row_sum_beta;
 } bla_gemm_epilogue;
 
 BLA_API bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,

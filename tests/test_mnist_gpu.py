@@ -80,16 +80,23 @@ def test_as_written_colsum_refused_where_reference_is_undefined(dev):
 
 
 def test_graph_replay_matches_eager(dev):
+    """Replaying the captured forward/backward + separate update is bit-identical to the eager step (same kernels, same order).
+    The one-graph step with the update folded into the weight-gradient products (W += lr * dZ.A^T through alpha / beta, b through the
+    scaled row sum; 6 launches) differs only by the rounding of that fused multiply-add."""
     x_raw, y = batch(256)
-    a = dev.mnist_nn.MnistNN(256); b = dev.mnist_nn.MnistNN(256)
-    for nn in (a, b):
+    a = dev.mnist_nn.MnistNN(256); b = dev.mnist_nn.MnistNN(256); c = dev.mnist_nn.MnistNN(256)
+    for nn in (a, b, c):
         nn.set_params(real_params()); nn.load_batch(x_raw, y)
+    p0 = real_params()
     for _ in range(3):
         a.train_step()
-        b.graph_step()
+        b.graph_step(with_update=False); b.apply()
+        c.graph_step()
     dev.sync()
-    for pa, pb in zip(a.get_params(), b.get_params()):
-        assert np.array_equal(pa, pb)                        # same kernels, same order: bit-identical
+    for pa, pb, pc, q in zip(a.get_params(), b.get_params(), c.get_params(), p0):
+        assert np.array_equal(pa, pb)
+        assert np.linalg.norm(pc - pa) <= 1e-6 * np.linalg.norm(pa) + 1e-9
+        assert np.linalg.norm((pc - q) - (pa - q)) <= 1e-5 * np.linalg.norm(pa - q) + 1e-9      # the update itself
 
 
 def test_ten_steps_track_the_oracle(dev, ora):
