@@ -159,8 +159,25 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
                 mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
                                       lambda: nn.apply(stream=stream), dist)
     else:
-        def step():
+        # one GPU: the fused-update step either replayed as a graph or issued directly (six launches per host call); which is faster
+        # depends on the host's launch rate, so both are tried on 100 untimed steps and the faster one is timed
+        def graph_mode():
             nn.graph_step(stream=stream, with_update=True)
+
+        def direct_mode():
+            nn.fused_step(stream=stream)
+        trial = {}
+        for name, fn in (("graph replay", graph_mode), ("direct launches", direct_mode)):
+            for _ in range(20):
+                fn()
+            barrier(); t_0 = time.perf_counter()
+            for _ in range(100):
+                fn()
+            barrier(); trial[name] = time.perf_counter() - t_0
+        launch_mode = min(trial, key=trial.get)
+        step = graph_mode if launch_mode == "graph replay" else direct_mode
+        nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+        exchange_name = "none (one GPU; step issued as " + launch_mode + ")"
     for _ in range(warmup):
         step()
     barrier()

@@ -111,6 +111,10 @@ class MnistNN:
     def graph_step(self, lr=LEARN_RATE, stream=None, with_update=True):
         native.check(self.L.bla_mnist_nn_graph_step(self.h, stream, lr, self.colsum_mode, int(with_update)))
 
+    def fused_step(self, lr=LEARN_RATE, stream=None):
+        """Forward, backward and update in six launches issued directly (update folded into the weight-gradient products; no gradient bucket)."""
+        native.check(self.L.bla_mnist_nn_fused_step(self.h, stream, None, None, lr, self.colsum_mode))
+
     def dp_step(self, exchange, lr=LEARN_RATE, stream=None):
         """One data-parallel step (forward, backward, direct-xGMI all-reduce fused with the update) as one graph launch."""
         native.check(self.L.bla_mnist_nn_dp_step(self.h, exchange.h, stream, lr, self.colsum_mode))

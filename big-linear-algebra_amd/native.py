@@ -90,6 +90,7 @@ SIGNATURES = {
     "bla_mnist_nn_get_params": (_I, [_VP, _VP]), "bla_mnist_nn_activation": (_I, [_VP, _I, C.POINTER(_VP), C.POINTER(_I)]),
     "bla_mnist_nn_forward_backward": (_I, [_VP, _VP, _VP, _VP, _I]), "bla_mnist_nn_apply": (_I, [_VP, _VP, _F]),
     "bla_mnist_nn_train_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]), "bla_mnist_nn_graph_step": (_I, [_VP, _VP, _F, _I, _I]),
+    "bla_mnist_nn_fused_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]),
     "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]),
     "bla_diag_mfma_rate": (_I, [_VP, _I, _I, _I, _VP]),
     "bla_graph_begin": (_I, [_VP]), "bla_graph_end": (_I, [_VP, C.POINTER(_VP)]), "bla_graph_launch": (_I, [_VP, _VP]),

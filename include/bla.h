@@ -291,6 +291,9 @@ BLA_API bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which /* 0..8: 
 BLA_API bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode);
 BLA_API bla_status bla_mnist_nn_apply(bla_mnist_nn* nn, void* stream, float lr /* reference: (float)-0.02 */);
 BLA_API bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode);
+/* One step with the update folded into the weight-gradient products (see graph_step below), issued directly on the stream: six launches
+ * from one host call, no gradient bucket.  Falls back to bla_mnist_nn_train_step where the fused form does not apply. */
+BLA_API bla_status bla_mnist_nn_fused_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode);
 /* Same step from the resident buffers, captured once into a hipGraph and replayed (launch-bound otherwise).  with_update = 1 and
  * BLA_COLSUM_INTENDED on the reference's layer sizes takes the fused form: the update rides inside the weight-gradient products
  * (W += lr * dZ.A^T, b += lr * rowsum(dZ)), six launches, and the gradient bucket is NOT written; with_update = 0 always fills it. */

@@ -84,15 +84,18 @@ def test_graph_replay_matches_eager(dev):
     The one-graph step with the update folded into the weight-gradient products (W += lr * dZ.A^T through alpha / beta, b through the
     scaled row sum; 6 launches) differs only by the rounding of that fused multiply-add."""
     x_raw, y = batch(256)
-    a = dev.mnist_nn.MnistNN(256); b = dev.mnist_nn.MnistNN(256); c = dev.mnist_nn.MnistNN(256)
-    for nn in (a, b, c):
+    a = dev.mnist_nn.MnistNN(256); b = dev.mnist_nn.MnistNN(256); c = dev.mnist_nn.MnistNN(256); d = dev.mnist_nn.MnistNN(256)
+    for nn in (a, b, c, d):
         nn.set_params(real_params()); nn.load_batch(x_raw, y)
     p0 = real_params()
     for _ in range(3):
         a.train_step()
         b.graph_step(with_update=False); b.apply()
         c.graph_step()
+        d.fused_step()                                       # the same six launches issued directly
     dev.sync()
+    for pc, pd in zip(c.get_params(), d.get_params()):
+        assert np.array_equal(pc, pd)
     for pa, pb, pc, q in zip(a.get_params(), b.get_params(), c.get_params(), p0):
         assert np.array_equal(pa, pb)
         assert np.linalg.norm(pc - pa) <= 1e-6 * np.linalg.norm(pa) + 1e-9

@@ -16,7 +16,9 @@ nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
 x = randint(7, (784, B), 256).astype(np.float32); lab = randint(8, (B,), 10)
 y = np.zeros((10, B), np.float32); y[lab, np.arange(B)] = 1
 nn.load_batch(x, y)
-f = nn.train_step if mode == "eager" else nn.graph_step
+def graph_unfused():
+    nn.graph_step(with_update=False); nn.apply()
+f = {"eager": nn.train_step, "graph": nn.graph_step, "graph_unfused": graph_unfused}[mode]
 for _ in range(5): f()
 bla.sync(); t0 = time.perf_counter()
 for _ in range(steps): f()
