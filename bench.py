@@ -136,10 +136,12 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
             algo = os.environ.get("BLA_DP_ALGO") or ("twoshot" if world >= 4 else "oneshot")
             exchange_name = ("one-kernel SUM all-reduce + SGD update (" + algo + "): every rank reads its peers' 235146-float gradient buckets "
                              + ("slice-wise (reduce-scatter, then the reduced slices) " if algo == "twoshot" else "")
-                             + "directly over xGMI (IPC-mapped fine-grained memory, flag-synchronised), whole step = one hipGraph launch")
+                             + "directly over xGMI (IPC-mapped fine-grained memory, flag-synchronised)")
+
+            dp_graph = [True]
 
             def step():
-                nn.dp_step(ex, stream=stream)
+                nn.dp_step(ex, stream=stream, graph=dp_graph[0])
             # two trial steps, then every rank reports whether a peer ever failed to show up (4 s time-out inside the kernel):
             # a node whose peer mappings do not behave falls back to the library collective instead of failing the run
             if os.environ.get("BLA_BENCH_NO_TRIAL") != "1":
@@ -148,6 +150,23 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
                 print(f"[bench] rank {rank}: direct exchange timed out, falling back to the RCCL all-reduce", file=sys.stderr, flush=True)
                 ex.close(); ex = None
                 nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+        if ex is not None:
+            # graph replay or direct launches: both tried on 60 untimed steps; every rank takes the choice that is faster for the slowest rank
+            trial = []
+            for g in (True, False):
+                dp_graph[0] = g
+                for _ in range(10):
+                    step()
+                barrier(); t_0 = time.perf_counter()
+                for _ in range(60):
+                    step()
+                barrier()
+                t = torch.tensor([time.perf_counter() - t_0], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial.append(float(t.item()))
+            dp_graph[0] = trial[0] <= trial[1]
+            exchange_name += "; step issued as " + ("one graph launch" if dp_graph[0] else "direct launches")
+            nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
         if ex is None:
             exchange_name = "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"
             params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)

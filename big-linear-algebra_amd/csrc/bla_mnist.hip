@@ -356,4 +356,22 @@ bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, floa
 	return BLA_OK;
 }
 
+/* The same data-parallel step issued directly on the stream (seven launches from one host call) instead of replayed as a graph; the two
+ * forms may be mixed freely (they share the bucket parity). */
+bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn && dp, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(colsum_mode == BLA_COLSUM_INTENDED, BLA_ERR_INVALID, "a sharded batch needs BLA_COLSUM_INTENDED (true row sums)");
+	BLA_REQUIRE(bla_dp_count(dp) == nn->count, BLA_ERR_SHAPE, "exchange bucket holds %zu floats, the trainer has %zu parameters", bla_dp_count(dp), nn->count);
+	hipStream_t s = pick_stream(stream);
+	const int par = (int)(nn->dp_steps & 1);
+	st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par));
+	if (st) return st;
+	st = bla_dp_allreduce_f32(dp, s, par, nullptr, nn->params, lr);
+	if (st) return st;
+	nn->dp_steps++;
+	return BLA_OK;
+}
+
 }  // extern "C"

@@ -115,9 +115,11 @@ class MnistNN:
         """Forward, backward and update in six launches issued directly (update folded into the weight-gradient products; no gradient bucket)."""
         native.check(self.L.bla_mnist_nn_fused_step(self.h, stream, None, None, lr, self.colsum_mode))
 
-    def dp_step(self, exchange, lr=LEARN_RATE, stream=None):
-        """One data-parallel step (forward, backward, direct-xGMI all-reduce fused with the update) as one graph launch."""
-        native.check(self.L.bla_mnist_nn_dp_step(self.h, exchange.h, stream, lr, self.colsum_mode))
+    def dp_step(self, exchange, lr=LEARN_RATE, stream=None, graph=True):
+        """One data-parallel step (forward, backward, direct-xGMI all-reduce fused with the update): one graph launch, or (graph=False)
+        the same seven launches issued directly from one host call."""
+        f = self.L.bla_mnist_nn_dp_step if graph else self.L.bla_mnist_nn_dp_step_direct
+        native.check(f(self.h, exchange.h, stream, lr, self.colsum_mode))
 
 
 class Exchange:

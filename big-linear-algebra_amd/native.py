@@ -99,7 +99,7 @@ SIGNATURES = {
     "bla_dp_export": (_I, [_VP, _VP]), "bla_dp_connect": (_I, [_VP, _VP]),
     "bla_dp_bucket": (_VP, [_VP, _I]), "bla_dp_count": (C.c_size_t, [_VP]),
     "bla_dp_allreduce_f32": (_I, [_VP, _VP, _I, _VP, _VP, _F]), "bla_dp_status": (_I, [_VP, C.POINTER(_I)]),
-    "bla_mnist_nn_dp_step": (_I, [_VP, _VP, _VP, _F, _I]),
+    "bla_mnist_nn_dp_step": (_I, [_VP, _VP, _VP, _F, _I]), "bla_mnist_nn_dp_step_direct": (_I, [_VP, _VP, _VP, _F, _I]),
 }
 
 

@@ -322,6 +322,8 @@ BLA_API bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, fl
 BLA_API bla_status bla_dp_status(bla_dp* dp, int* status);
 /* forward + backward + exchange + update of one data-parallel step as one graph launch (BLA_COLSUM_INTENDED only) */
 BLA_API bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
+/* the same step issued directly on the stream (seven launches from one host call); may be mixed with the graph form */
+BLA_API bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ for rnd in range(3):
 res["target"] = tgt.numpy()
 res["status_a"] = np.int32(ex.status())
 
-# --- B: data-parallel MNIST-NN steps, one graph launch each ----------------------------------------------------------
+# --- B: data-parallel MNIST-NN steps (graph launch / direct launches) ----------------------------------------------------------
 gB = per * world
 nn = mn.MnistNN(per, colsum_mode=mn.COLSUM_INTENDED)
 z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
@@ -60,8 +60,8 @@ lo, hi = mn.shard_columns(gB, world, rank)
 nn.load_batch(np.ascontiguousarray(x_raw[:, lo:hi]), np.ascontiguousarray(y[:, lo:hi]))
 ex2 = mn.Exchange(rank, world, nn.count, file_all_gather("b"))
 t0 = time.perf_counter()
-for _ in range(steps):
-    nn.dp_step(ex2)
+for i in range(steps):
+    nn.dp_step(ex2, graph=(i % 3 != 2))      # graph replays and direct launches mixed: they share the bucket parity
 native.sync()
 res["wall_per_step_us"] = np.float64((time.perf_counter() - t0) / steps * 1e6)
 res["params"] = mn.flatten_params(nn.get_params())
