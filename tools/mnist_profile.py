@@ -18,7 +18,7 @@ y = np.zeros((10, B), np.float32); y[lab, np.arange(B)] = 1
 nn.load_batch(x, y)
 def graph_unfused():
     nn.graph_step(with_update=False); nn.apply()
-f = {"eager": nn.train_step, "graph": nn.graph_step, "graph_unfused": graph_unfused}[mode]
+f = {"eager": nn.train_step, "graph": nn.graph_step, "graph_unfused": graph_unfused, "direct": nn.fused_step}[mode]
 for _ in range(5): f()
 bla.sync(); t0 = time.perf_counter()
 for _ in range(steps): f()
