@@ -169,16 +169,26 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
             dp_graph[0] = trial[0] <= trial[1]
             exchange_name += "; step issued as " + ("one graph launch" if dp_graph[0] else "direct launches")
             nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
-        if ex is None:
-            exchange_name = "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"
+            if not all_agree(ex.status() == 0):    # a peer went missing during the 140 trial steps
+                print(f"[bench] rank {rank}: direct exchange timed out during the launch-mode trial, falling back to the RCCL all-reduce", file=sys.stderr, flush=True)
+                ex.close(); ex = None
+
+        keep = []
+
+        def library_collective_step():
+            """the fallback: gradients into a torch-owned bucket, RCCL SUM all-reduce, update"""
             params_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
             grads_t = torch.zeros(nn.count, device="cuda", dtype=torch.float32)
+            keep.extend([params_t, grads_t])
             torch.cuda.synchronize()
             nn.use_buckets(params_t.data_ptr(), grads_t.data_ptr())
-
-            def step():
-                mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
-                                      lambda: nn.apply(stream=stream), dist)
+            nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+            return lambda: mn.data_parallel_step(lambda: nn.graph_step(stream=stream, with_update=False), grads_t,
+                                                 lambda: nn.apply(stream=stream), dist)
+        rccl_name = "RCCL SUM all-reduce of the flat 235146-float gradient bucket per step"
+        if ex is None:
+            exchange_name = rccl_name
+            step = library_collective_step()
     else:
         # one GPU: the fused-update step either replayed as a graph or issued directly (six launches per host call); which is faster
         # depends on the host's launch rate, so both are tried on 100 untimed steps and the faster one is timed
@@ -200,29 +210,41 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
         step = graph_mode if launch_mode == "graph replay" else direct_mode
         nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
         exchange_name = "none (one GPU; step issued as " + launch_mode + ")"
-    for _ in range(warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    p = bla.mnist_nn.flatten_params(nn.get_params())
-    assert np.isfinite(p).all()
+
+    def measure(step):
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, bla.mnist_nn.flatten_params(nn.get_params())
+
+    wall, p = measure(step)
     if ex is not None:
-        assert ex.status() == 0, "a gradient exchange timed out waiting for a peer"
         import torch
-        # every rank must hold bit-identical parameters (the sums are taken in rank order everywhere)
+        # every rank must hold bit-identical, finite parameters (the sums are taken in rank order everywhere) and no exchange may have
+        # timed out; a node where that does not hold is measured again over the library collective instead of failing the run
         digest = torch.tensor([float(np.frombuffer(p.tobytes(), np.uint32).astype(np.uint64).sum() % (1 << 40))], device="cuda", dtype=torch.float64)
         lo, hi = digest.clone(), digest.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert float(lo.item()) == float(hi.item()), "ranks hold different parameters after the data-parallel steps"
+        good = bool(np.isfinite(p).all()) and ex.status() == 0 and float(lo.item()) == float(hi.item())
+        if os.environ.get("BLA_BENCH_REHEARSE_RECHECK") == "1":   # rehearsal of the re-measure path below
+            good = False
+        if not all_agree(good):
+            print(f"[bench] rank {rank}: direct exchange failed its end-of-run check (status {ex.status()}, digests {lo.item()} / {hi.item()}); "
+                  "measuring again over the RCCL all-reduce", file=sys.stderr, flush=True)
+            ex.close(); ex = None
+            exchange_name = rccl_name + " (the direct peer-read exchange failed its check on this node)"
+            wall, p = measure(library_collective_step())
+    assert np.isfinite(p).all()
     if rank != 0:
         return None
     flop_per_sample = 1007104   # GEMMs only, fwd 469,504 + bwd 537,600
