@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 			deliver(a, i, s);
 		}
 	}
-	// the workgroup that leaves phase A last publishes "my reduced slice is ready" to every peer
+	// the workgroup that leaves phase A last publishes "my reduced slice is ready" to every peer (every wave first waits for its own
+	// stores to be acknowledged: the barrier alone does not, and lane 0's fence below only covers its own wave's queue)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		__threadfence_system();
