@@ -218,20 +218,28 @@ __global__ void __launch_bounds__(256) conv_table_kernel(int2* tab, ConvGeom g) 
 	tab[kidx] = make_int2(c * g.h * g.w + dy * g.w + dx, (dy & 0xffff) | (dx << 16));
 }
 
+constexpr int kConvTabLds = 2048;   // tap-table entries a workgroup keeps in LDS (16 KB)
+// bx = output tile, by = K-split (FWD) or image * psplits + K-split (WGRAD), bz = image (FWD)
 template <int MODE, bool VEC>
-__global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_implicit_body(ConvArgs p, const int bx, const int by, const int bz, float (*red)[32 * 33], int2* s_tab) {
 	constexpr int NW = 4, PF = 8;
 	typedef float f32x16 __attribute__((ext_vector_type(16)));
-	__shared__ float red[NW][32 * 33];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l31 = lane & 31, h = lane >> 5;
-	const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+	const int tile_m = bx / p.tiles_n, tile_n = bx % p.tiles_n;
 	const int m0 = tile_m * 32, n0 = tile_n * 32;
-	const int image = MODE == CONV_FWD ? (int)blockIdx.z : (int)blockIdx.y / p.psplits;
-	const int ks = MODE == CONV_FWD ? (int)blockIdx.y : (int)blockIdx.y % p.psplits;
+	const int image = MODE == CONV_FWD ? bz : by / p.psplits;
+	const int ks = MODE == CONV_FWD ? by : by % p.psplits;
 	p.img += (size_t)image * p.img_stride; p.A += (size_t)image * p.a_stride;
 	if (MODE == CONV_FWD) { p.out += (size_t)image * p.out_stride; if (p.slab) p.slab += (size_t)image * p.splits * p.M * p.N; }
-	const int split_end = min(p.K, (ks + 1) * p.k_per_split);
+	const int split_begin = ks * p.k_per_split, split_end = min(p.K, (ks + 1) * p.k_per_split);
+	// FWD: the tap table of this workgroup's K range goes to LDS once (one coalesced fetch) -- looked up from global memory, every round
+	// of operand loads would be two dependent round trips (table entry, then the pixel it points to)
+	const bool tab_lds = MODE == CONV_FWD && split_end - split_begin <= kConvTabLds && split_end > split_begin;
+	if (tab_lds) {
+		for (int i = threadIdx.x; i < split_end - split_begin; i += 256) s_tab[i] = p.tab[split_begin + i];
+		__syncthreads();
+	}
 	const int k_begin = min(split_end, ks * p.k_per_split + wave * p.kw), k_end = min(split_end, k_begin + p.kw);
 	const int arow = min(m0 + l31, p.M - 1);
 	const int ncol = min(n0 + l31, p.N - 1);
@@ -259,7 +267,7 @@ __global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
 		if (MODE == CONV_FWD) {
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				int2 t = p.tab[min(kb + j, p.K - 1)];
+				int2 t = tab_lds ? s_tab[min(kb + j, split_end - 1) - split_begin] : p.tab[min(kb + j, p.K - 1)];
 				int yy = y0 + (short)(t.y & 0xffff), xx = x0 + (t.y >> 16);
 				bool ok = kb + j < k_end && (unsigned)yy < (unsigned)g.h && (unsigned)xx < (unsigned)g.w;
 				float v = p.img[ok ? t.x + base : 0];
@@ -298,9 +306,32 @@ __global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
 		int r = e >> 5, c = e & 31;
 		float s = (red[0][r * 33 + c] + red[1][r * 33 + c]) + (red[2][r * 33 + c] + red[3][r * 33 + c]);
 		if (m0 + r < p.M && n0 + c < p.N) {
-			if (p.splits > 1) p.slab[((size_t)blockIdx.y * p.M + m0 + r) * p.N + n0 + c] = s;
+			if (p.splits > 1) p.slab[((size_t)by * p.M + m0 + r) * p.N + n0 + c] = s;
 			else p.out[(size_t)(m0 + r) * p.ldo + n0 + c] = s;
 		}
+	}
+}
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
+	__shared__ float red[4][32 * 33];
+	__shared__ int2 s_tab[MODE == CONV_FWD ? kConvTabLds : 1];
+	conv_implicit_body<MODE, VEC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, red, s_tab);
+}
+
+// Both gradients of one convolution in ONE launch: the weight gradient (WGRAD on the forward input) and the data gradient (FWD on del_y
+// with the flipped kernels) depend only on del_y, the reference runs them one after the other (lib/conv.c:221-228); a single image fills
+// a fraction of the chip with either, so their workgroups share a grid.  Linear block index: [0, blocks_w) = weight gradient
+// (tile fastest, then split), the rest = data gradient (tile, split, image).
+template <bool VECW, bool VECD>
+__global__ void __launch_bounds__(256) conv_backward_pair_kernel(ConvArgs w, ConvArgs d, unsigned blocks_w, unsigned tiles_w, unsigned tiles_d, unsigned splits_d) {
+	__shared__ float red[4][32 * 33];
+	__shared__ int2 s_tab[kConvTabLds];
+	const unsigned b = blockIdx.x;
+	if (b < blocks_w) conv_implicit_body<CONV_WGRAD, VECW>(w, (int)(b % tiles_w), (int)(b / tiles_w), 0, red, s_tab);
+	else {
+		const unsigned e = b - blocks_w;
+		conv_implicit_body<CONV_FWD, VECD>(d, (int)(e % tiles_d), (int)(e / tiles_d % splits_d), (int)(e / tiles_d / splits_d), red, s_tab);
 	}
 }
 
@@ -308,15 +339,21 @@ __global__ void __launch_bounds__(256) conv_implicit_kernel(ConvArgs p) {
 // (Measured and not kept: folding inside the gather kernel -- arrival counter per tile, last workgroup sums the partials, as the
 // wave-split-K GEMM can -- to save this launch.  The agent-scope release/acquire per workgroup costs more than the launch:
 // 128->128 @32x32 forward 27.9 us instead of 18.9, both gradients 59.7 instead of 42.5.)
-__global__ void __launch_bounds__(kThreads) conv_slab_reduce_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_slab_reduce_body(const ConvArgs& p, unsigned bx, unsigned nbx, unsigned image) {
 	size_t total = (size_t)p.M * p.N;
-	const float* slab = p.slab + (size_t)blockIdx.y * p.splits * total;
-	float* out = p.out + (size_t)blockIdx.y * p.out_stride;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+	const float* slab = p.slab + (size_t)image * p.splits * total;
+	float* out = p.out + (size_t)image * p.out_stride;
+	for (size_t i = (size_t)bx * blockDim.x + threadIdx.x; i < total; i += (size_t)nbx * blockDim.x) {
 		float s = 0.f;
 		for (int z = 0; z < p.splits; z++) s += slab[(size_t)z * total + i];
 		out[(i / p.N) * p.ldo + i % p.N] = s;
 	}
+}
+__global__ void __launch_bounds__(kThreads) conv_slab_reduce_kernel(ConvArgs p) { conv_slab_reduce_body(p, blockIdx.x, gridDim.x, blockIdx.y); }
+// the folds of both gradients in one launch: blocks [0, blocks_w) fold the weight-gradient slabs, the rest the data gradient's (per image)
+__global__ void __launch_bounds__(kThreads) conv_slab_reduce_pair_kernel(ConvArgs w, ConvArgs d, unsigned blocks_w, unsigned blocks_d) {
+	if (blockIdx.x < blocks_w) { if (w.splits > 1) conv_slab_reduce_body(w, blockIdx.x, blocks_w, 0); }
+	else if (d.splits > 1) { const unsigned e = blockIdx.x - blocks_w; conv_slab_reduce_body(d, e % blocks_d, blocks_d, e / blocks_d); }
 }
 
 // kt[c][f][p][q] = kern[f][c][k-1-p][k-1-q]: the kernels of the data-gradient convolution
@@ -432,6 +469,31 @@ static bool use_tiled_gather(const ConvArgs& a, int batch, int mode) {
 	return a.K % 16 == 0 && kk >= 16384 && tiles * batch >= 128;   // a.K = output pixels per image here
 }
 
+// tiling / K-splitting of the 32x32 wave-split-K gather kernel for one pass; a.batch and the strides are set
+template <int MODE>
+static bla_status plan_wsk_gather(ConvArgs& a, int batch, size_t* slab_bytes, dim3* grid, bool* vec, int target_wgs = 768) {
+	a.tiles_n = (a.N + 31) / 32;
+	int tiles = ((a.M + 31) / 32) * a.tiles_n;
+	// long contractions over few tiles are latency-bound: cut K over workgroups until ~3 of them sit on every CU,
+	// keeping >= 128 k per workgroup (a batch multiplies the workgroups of a forward pass, and the K-splits of a weight gradient)
+	int splits = (target_wgs + tiles * batch - 1) / (tiles * batch);
+	if (splits > a.K / 128) splits = a.K / 128;
+	if (splits < 1) splits = 1;
+	if (splits > 32) splits = 32;
+	a.k_per_split = ((a.K + splits - 1) / splits + 31) / 32 * 32;
+	splits = (a.K + a.k_per_split - 1) / a.k_per_split;
+	a.kw = a.k_per_split / 4;   // multiple of 8
+	a.slab = nullptr;
+	a.psplits = splits;
+	const bool wgrad = MODE == CONV_WGRAD;
+	a.splits = wgrad ? splits * batch : splits;          // slabs folded into one output
+	*slab_bytes = a.splits > 1 ? (size_t)splits * batch * a.M * a.N * sizeof(float) : 0;
+	BLA_REQUIRE((long)splits * batch <= 65535 && batch <= 65535, BLA_ERR_INVALID, "batch %d too large for one launch", batch);
+	*grid = dim3((unsigned)tiles, (unsigned)(wgrad ? splits * batch : splits), (unsigned)(wgrad ? 1 : batch));
+	*vec = a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0 && a.a_stride % 4 == 0;
+	return BLA_OK;
+}
+
 template <int MODE>
 static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, size_t img_stride = 0, size_t out_stride = 0, size_t a_stride = 0) {
 	a.batch = batch; a.img_stride = img_stride; a.out_stride = out_stride; a.a_stride = a_stride;
@@ -474,35 +536,57 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
 		return gather_gemm(s, 2, batch, a.M, a.N, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, ptab, a.tab, a.g.h, a.g.w, a.K, (int)img_stride);
 	}
-	a.tiles_n = (a.N + 31) / 32;
-	int tiles = ((a.M + 31) / 32) * a.tiles_n;
-	// long contractions over few tiles are latency-bound: cut K over workgroups until ~3 of them sit on every CU,
-	// keeping >= 128 k per workgroup (a batch multiplies the workgroups of a forward pass, and the K-splits of a weight gradient)
-	int splits = (768 + tiles * batch - 1) / (tiles * batch);
-	if (splits > a.K / 128) splits = a.K / 128;
-	if (splits < 1) splits = 1;
-	if (splits > 32) splits = 32;
-	a.k_per_split = ((a.K + splits - 1) / splits + 31) / 32 * 32;
-	splits = (a.K + a.k_per_split - 1) / a.k_per_split;
-	a.kw = a.k_per_split / 4;   // multiple of 8
-	a.slab = nullptr;
-	a.psplits = splits;
+	size_t slab_bytes;
+	dim3 grid;
+	bool vec;
+	bla_status st = plan_wsk_gather<MODE>(a, batch, &slab_bytes, &grid, &vec);
+	if (st) return st;
 	const bool wgrad = MODE == CONV_WGRAD;
-	a.splits = wgrad ? splits * batch : splits;          // slabs folded into one output
 	if (a.splits > 1) {
 		void* ws;
-		size_t slabs = (size_t)splits * batch;
-		bla_status st = ensure_workspace(slabs * a.M * a.N * sizeof(float), &ws);
+		st = ensure_workspace(slab_bytes, &ws);
 		if (st) return st;
 		a.slab = (float*)ws;
 	}
-	BLA_REQUIRE((long)splits * batch <= 65535 && batch <= 65535, BLA_ERR_INVALID, "batch %d too large for one launch", batch);
-	dim3 grid((unsigned)tiles, (unsigned)(wgrad ? splits * batch : splits), (unsigned)(wgrad ? 1 : batch));
-	bool vec = a.K % 4 == 0 && a.K >= 4 && a.lda % 4 == 0 && (uintptr_t)a.A % 16 == 0 && a.a_stride % 4 == 0;
 	if (vec) hipLaunchKernelGGL((conv_implicit_kernel<MODE, true>), grid, dim3(256), 0, s, a);
 	else hipLaunchKernelGGL((conv_implicit_kernel<MODE, false>), grid, dim3(256), 0, s, a);
 	if (a.splits > 1)
 		hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(grid_for((size_t)a.M * a.N), (unsigned)(wgrad ? 1 : batch)), dim3(kThreads), 0, s, a);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
+// Weight gradient (w: WGRAD on the forward input) and data gradient (d: FWD on del_y with the flipped kernels) of one convolution
+// as one gather launch + one fold launch; only for shapes that stay on the 32x32 kernel (a single image, a small batch).
+static bla_status launch_backward_pair(hipStream_t s, ConvArgs& w, ConvArgs& d, int batch) {
+	size_t bytes_w, bytes_d;
+	dim3 gw, gd;
+	bool vw, vd;
+	const int target = 384;   // workgroups per product: the two share the chip (768 for a product launched alone); measured 128 ... 768
+	bla_status st = plan_wsk_gather<CONV_WGRAD>(w, batch, &bytes_w, &gw, &vw, target);
+	if (st) return st;
+	st = plan_wsk_gather<CONV_FWD>(d, batch, &bytes_d, &gd, &vd, target);
+	if (st) return st;
+	bytes_w = (bytes_w + 255) / 256 * 256;
+	if (bytes_w + bytes_d > 0) {
+		void* ws;
+		st = ensure_workspace(bytes_w + bytes_d, &ws);
+		if (st) return st;
+		if (w.splits > 1) w.slab = (float*)ws;
+		if (d.splits > 1) d.slab = (float*)((char*)ws + bytes_w);
+	}
+	const unsigned blocks_w = gw.x * gw.y, blocks_d = gd.x * gd.y * gd.z;
+	dim3 grid(blocks_w + blocks_d);
+#define BLA_PAIR(VW, VD) hipLaunchKernelGGL((conv_backward_pair_kernel<VW, VD>), grid, dim3(256), 0, s, w, d, blocks_w, gw.x, gd.x, gd.y)
+	if (vw && vd) BLA_PAIR(true, true);
+	else if (vw) BLA_PAIR(true, false);
+	else if (vd) BLA_PAIR(false, true);
+	else BLA_PAIR(false, false);
+#undef BLA_PAIR
+	if (w.splits > 1 || d.splits > 1) {
+		const unsigned rw = grid_for((size_t)w.M * w.N), rd = grid_for((size_t)d.M * d.N);
+		hipLaunchKernelGGL(conv_slab_reduce_pair_kernel, dim3(rw + rd * (unsigned)batch), dim3(kThreads), 0, s, w, d, rw, rd);
+	}
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -638,6 +722,28 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 	hipStream_t s = pick_stream(stream);
 	Geometry gm = same_geometry(h, w, k, stride);
 	const size_t x_sz = (size_t)c_in * h * w, y_sz = (size_t)f_n * gm.ho * gm.wo;
+	if (d_del_kern && d_del_x && stride == 1) {
+		// both gradients, both on the latency-bound kernel: one gather launch and one fold launch for the two
+		BLA_REQUIRE(d_x && d_kern && d_scratch, BLA_ERR_INVALID, "the gradients need the forward input, the kernels and a scratch buffer of F*C*k*k floats");
+		ConvArgs aw, ad;
+		aw.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
+		aw.A = d_del_y; aw.lda = gm.ho * gm.wo; aw.img = d_x; aw.out = d_del_kern; aw.ldo = k * k * c_in;
+		aw.M = f_n; aw.N = k * k * c_in; aw.K = gm.ho * gm.wo;
+		aw.batch = batch; aw.img_stride = x_sz; aw.out_stride = 0; aw.a_stride = y_sz;
+		ad.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
+		ad.A = d_scratch; ad.lda = k * k * f_n; ad.img = d_del_y; ad.out = d_del_x; ad.ldo = h * w;
+		ad.M = c_in; ad.N = h * w; ad.K = k * k * f_n;
+		ad.batch = batch; ad.img_stride = y_sz; ad.out_stride = x_sz; ad.a_stride = 0;
+		if (!use_tiled_gather(aw, batch, 2) && !use_tiled_gather(ad, batch, 1)) {
+			st = get_table(s, aw.g, &aw.tab);
+			if (st) return st;
+			st = get_table(s, ad.g, &ad.tab);
+			if (st) return st;
+			hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+			BLA_HIP(hipGetLastError());
+			return launch_backward_pair(s, aw, ad, batch);
+		}
+	}
 	if (d_del_kern) {
 		BLA_REQUIRE(d_x, BLA_ERR_INVALID, "weight gradient needs the forward input");
 		ConvArgs a;
