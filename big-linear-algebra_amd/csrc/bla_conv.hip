@@ -94,7 +94,9 @@ __device__ __forceinline__ double gn_block_sum(double v) {
 
 template <bool RELU>   // RELU: multi_channel_relu fused behind the normalisation (model/cifar_unet.c:1046-1047,1056-1057)
 __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
-                                                                 float* __restrict__ means, int channels, int group_size, int hw) {
+                                                                 float* __restrict__ means, int channels, int group_size, int hw,
+                                                                 const unsigned char* __restrict__ drop = nullptr, float* __restrict__ dropped = nullptr) {
+	// drop / dropped: _dropout (model/cifar_unet.c:1032-1042, :1058) in the same pass -- dropped = drop ? 0 : out
 	int g = blockIdx.x;
 	int nch = min(group_size, channels - g * group_size);
 	size_t off = (size_t)g * group_size * hw;
@@ -115,60 +117,131 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __r
 		for (int i = 0; i < kGnRegs; i++) {   // (x - mean) / (stdev + 0), lib/norm.c:44
 			int j = t + i * kGnThreads;
 			float y = (v[i] - mean) / var;
-			if (j < n) out[off + j] = RELU && y < 0.f ? 0.f : y;
+			y = RELU && y < 0.f ? 0.f : y;
+			if (j < n) { out[off + j] = y; if (dropped) dropped[off + j] = drop[off + j] ? 0.f : y; }
 		}
 		return;
 	}
 	double s = 0;
+#pragma unroll 8
 	for (int i = t; i < n; i += kGnThreads) s += in[off + i];
 	float mean = (float)(gn_block_sum(s) / (double)n);
 	double q = 0;
+#pragma unroll 8
 	for (int i = t; i < n; i += kGnThreads) { float v = in[off + i] - mean; q += (double)v * v; }
 	float var = (float)(gn_block_sum(q) / (double)n);
 	if (t == 0) { means[g] = mean; stdevs[g] = var; }
+#pragma unroll 8
 	for (int i = t; i < n; i += kGnThreads) {
 		float y = (in[off + i] - mean) / var;
-		out[off + i] = RELU && y < 0.f ? 0.f : y;
+		y = RELU && y < 0.f ? 0.f : y;
+		out[off + i] = y;
+		if (dropped) dropped[off + i] = drop[off + i] ? 0.f : y;
 	}
 }
 
 // lib/norm.c:52-93
 __global__ void __launch_bounds__(kGnThreads) group_norm_ddx_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
                                                                      const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
-                                                                     int group_size, int hw) {
+                                                                     int group_size, int hw, const float* __restrict__ relu_gate = nullptr,
+                                                                     const float* __restrict__ addend = nullptr) {
+	// relu_gate: multi_channel_relu_ddx on the way in (source counts as 0 where the forward ReLU output was <= 0, model/cifar_unet.c:1204);
+	// addend: the residual branch's gradient on the way out (dest = group_norm_ddx(...) + addend, :1219)
 	int g = blockIdx.x;
 	int nch = min(group_size, channels - g * group_size);
 	size_t off = (size_t)g * group_size * hw;
 	int n = nch * hw;
 	const int t = threadIdx.x;
 	float mean = means[g], sd = stdevs[g];
-	if (n <= kGnThreads * (kGnRegs / 2)) {   // two register copies (source, normalised data): 16 each
+	if (n <= kGnThreads * (kGnRegs / 2)) {   // two register copies (source, normalised data): 16 each (32 each spills)
 		float sv[kGnRegs / 2], nv[kGnRegs / 2];
 		double gs = 0, gws = 0;
 #pragma unroll
 		for (int i = 0; i < kGnRegs / 2; i++) {
 			int j = t + i * kGnThreads;
 			sv[i] = j < n ? source[off + j] : 0.f;
+			if (relu_gate && j < n && relu_gate[off + j] <= 0.f) sv[i] = 0.f;
 			nv[i] = j < n ? (data[off + j] - mean) / sd : 0.f;
 			gs += sv[i]; gws += (double)nv[i] * sv[i];
 		}
 		float fgs = (float)(gn_block_sum(gs) / (double)n);
 		float fgws = (float)(gn_block_sum(gws) / (double)n);
 #pragma unroll
-		for (int i = 0; i < kGnRegs / 2; i++) { int j = t + i * kGnThreads; if (j < n) dest[off + j] = (sv[i] - fgs - nv[i] * fgws) / sd; }
+		for (int i = 0; i < kGnRegs / 2; i++) {
+			int j = t + i * kGnThreads;
+			if (j < n) { float d = (sv[i] - fgs - nv[i] * fgws) / sd; dest[off + j] = addend ? d + addend[off + j] : d; }
+		}
 		return;
 	}
 	double gs = 0, gws = 0;
+	// (unrolled: one workgroup walks a whole group, so the loads of several iterations must be in flight together)
+#pragma unroll 8
 	for (int i = t; i < n; i += kGnThreads) {
 		float wgt = (data[off + i] - mean) / sd;
-		gs += source[off + i];
-		gws += (double)wgt * source[off + i];
+		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
+		gs += sv;
+		gws += (double)wgt * sv;
 	}
 	float fgs = (float)(gn_block_sum(gs) / (double)n);
 	float fgws = (float)(gn_block_sum(gws) / (double)n);
+#pragma unroll 8
 	for (int i = t; i < n; i += kGnThreads) {
 		float nv = (data[off + i] - mean) / sd;
-		dest[off + i] = (source[off + i] - fgs - nv * fgws) / sd;
+		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
+		float d = (sv - fgs - nv * fgws) / sd;
+		dest[off + i] = addend ? d + addend[off + i] : d;
+	}
+}
+
+// Groups too large for the one-pass path: one workgroup per group is bound by a single CU's instruction rate (24 us for 32 channels x 32x32),
+// so the group is cut into slices of kGnSlice elements over blockIdx.x -- partial sums (fp64) per slice, then every slice's workgroup adds the
+// partials in slice order (identical totals everywhere, deterministic) and writes its part.  Same gate / addend options as the kernel above.
+constexpr int kGnSlice = 2048, kGnSliceThreads = 256;
+
+__global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_stats_kernel(const float* __restrict__ source, const float* __restrict__ data,
+                                                                                const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
+                                                                                int group_size, int hw, const float* __restrict__ relu_gate, double2* partials) {
+	const int g = blockIdx.y, slice = blockIdx.x;
+	const int nch = min(group_size, channels - g * group_size);
+	const size_t off = (size_t)g * group_size * hw;
+	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
+	const float mean = means[g], sd = stdevs[g];
+	double gs = 0, gws = 0;
+	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
+		float wgt = (data[off + i] - mean) / sd;
+		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
+		gs += sv;
+		gws += (double)wgt * sv;
+	}
+	__shared__ double sh[2][kGnSliceThreads / 64];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { gs += __shfl_down(gs, o, 64); gws += __shfl_down(gws, o, 64); }
+	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = gs; sh[1][threadIdx.x >> 6] = gws; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double a = 0, b = 0;
+		for (int i = 0; i < kGnSliceThreads / 64; i++) { a += sh[0][i]; b += sh[1][i]; }
+		partials[(size_t)g * gridDim.x + slice] = make_double2(a, b);
+	}
+}
+
+__global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_apply_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
+                                                                                const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
+                                                                                int group_size, int hw, const float* __restrict__ relu_gate,
+                                                                                const float* __restrict__ addend, const double2* __restrict__ partials) {
+	const int g = blockIdx.y, slice = blockIdx.x;
+	const int nch = min(group_size, channels - g * group_size);
+	const size_t off = (size_t)g * group_size * hw;
+	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
+	const float mean = means[g], sd = stdevs[g];
+	double a = 0, b = 0;
+	for (unsigned i = 0; i < gridDim.x; i++) { double2 q = partials[(size_t)g * gridDim.x + i]; a += q.x; b += q.y; }   // slice order: same totals in every workgroup
+	const float fgs = (float)(a / (double)n), fgws = (float)(b / (double)n);
+	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
+		float nv = (data[off + i] - mean) / sd;
+		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
+		float d = (sv - fgs - nv * fgws) / sd;
+		dest[off + i] = addend ? d + addend[off + i] : d;
 	}
 }
 
@@ -205,7 +278,18 @@ struct ConvArgs {
 	int batch, psplits;
 	size_t img_stride, out_stride, a_stride;
 	ConvGeom g;
+	// forward epilogue (the adds the U-Net puts behind a conv, model/cifar_unet.c:1053,1067-1071): out = conv + ep_bias[row];
+	// ep_out2 = out + ep_add (same layout as out).  Applied where the output is stored: in the gather kernel or in the slab fold.
+	const float* ep_bias = nullptr;
+	const float* ep_add = nullptr;
+	float* ep_out2 = nullptr;
 };
+
+__device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
+	if (p.ep_bias) s += p.ep_bias[row];
+	out[(size_t)row * p.ldo + col] = s;
+	if (p.ep_out2) p.ep_out2[image_off + (size_t)row * p.ldo + col] = s + p.ep_add[image_off + (size_t)row * p.ldo + col];
+}
 
 enum { CONV_FWD = 0, CONV_WGRAD = 1 };
 
@@ -307,7 +391,7 @@ __device__ __forceinline__ void conv_implicit_body(ConvArgs p, const int bx, con
 		float s = (red[0][r * 33 + c] + red[1][r * 33 + c]) + (red[2][r * 33 + c] + red[3][r * 33 + c]);
 		if (m0 + r < p.M && n0 + c < p.N) {
 			if (p.splits > 1) p.slab[((size_t)by * p.M + m0 + r) * p.N + n0 + c] = s;
-			else p.out[(size_t)(m0 + r) * p.ldo + n0 + c] = s;
+			else conv_store(p, p.out, MODE == CONV_FWD ? (size_t)image * p.out_stride : 0, m0 + r, n0 + c, s);
 		}
 	}
 }
@@ -346,7 +430,7 @@ __device__ __forceinline__ void conv_slab_reduce_body(const ConvArgs& p, unsigne
 	for (size_t i = (size_t)bx * blockDim.x + threadIdx.x; i < total; i += (size_t)nbx * blockDim.x) {
 		float s = 0.f;
 		for (int z = 0; z < p.splits; z++) s += slab[(size_t)z * total + i];
-		out[(i / p.N) * p.ldo + i % p.N] = s;
+		conv_store(p, out, (size_t)image * p.out_stride, (int)(i / p.N), (int)(i % p.N), s);
 	}
 }
 __global__ void __launch_bounds__(kThreads) conv_slab_reduce_kernel(ConvArgs p) { conv_slab_reduce_body(p, blockIdx.x, gridDim.x, blockIdx.y); }
@@ -591,6 +675,27 @@ static bla_status launch_backward_pair(hipStream_t s, ConvArgs& w, ConvArgs& d, 
 	return BLA_OK;
 }
 
+static bla_status launch_group_norm_ddx(hipStream_t s, const float* source, float* dest, const float* data, const float* means, const float* stdevs, int channels,
+                                        int group_size, int hw, const float* relu_gate, const float* addend) {
+	const int groups = (channels + group_size - 1) / group_size;
+	const long n_max = (long)(channels < group_size ? channels : group_size) * hw;
+	if (n_max <= kGnThreads * (kGnRegs / 2)) {
+		hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kGnThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw, relu_gate, addend);
+	} else {
+		const unsigned slices = (unsigned)((n_max + kGnSlice - 1) / kGnSlice);
+		BLA_REQUIRE(groups <= 65535, BLA_ERR_INVALID, "too many groups (%d)", groups);
+		void* ws;
+		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
+		if (st) return st;
+		hipLaunchKernelGGL(group_norm_ddx_stats_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
+		                   relu_gate, (double2*)ws);
+		hipLaunchKernelGGL(group_norm_ddx_apply_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
+		                   relu_gate, addend, (const double2*)ws);
+	}
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 }  // namespace bla
 
 using namespace bla;
@@ -697,7 +802,8 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
 
 /* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
  * same values as conv()'s `output` (lib/conv.c:205-212, intended composition), any stride. */
-static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
+static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride,
+                                 const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -710,8 +816,21 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	if (st) return st;
 	a.A = d_kern; a.lda = k * k * c_in; a.img = d_x; a.out = d_out; a.ldo = gm.ho * gm.wo;
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
+	const bool ep = ep_bias || ep_out2;
+	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
+	if (ep && use_tiled_gather(a, batch, 1)) {   // the tiled kernels carry no epilogue: run the adds behind them
+		st = launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
+		for (int b = 0; b < batch && !st; b++) {
+			float* o = d_out + (size_t)b * f_n * a.N;
+			if (ep_bias) st = bla_add_tile_columns_f32(stream, o, f_n, a.N, ep_bias, 1);
+			if (!st && ep_out2) st = bla_sum_f32(stream, ep_out2 + (size_t)b * f_n * a.N, o, ep_add + (size_t)b * f_n * a.N, (size_t)f_n * a.N);
+		}
+		return st;
+	}
+	a.ep_bias = ep_bias; a.ep_add = ep_add; a.ep_out2 = ep_out2;
 	return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
 }
+
 
 static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
                                   float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
@@ -811,7 +930,8 @@ bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, flo
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel<false>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
+	hipLaunchKernelGGL(group_norm_kernel<false>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw,
+	                   (const unsigned char*)nullptr, (float*)nullptr);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -822,7 +942,8 @@ bla_status bla_group_norm_relu_f32(void* stream, const float* d_in, float* d_out
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw);
+	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw,
+	                   (const unsigned char*)nullptr, (float*)nullptr);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -833,11 +954,35 @@ bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_source && d_dest && d_data && d_means && d_stdevs, BLA_ERR_INVALID, "null operand");
+	return launch_group_norm_ddx(pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels, group_size, hw, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace bla {
+bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
+                                   const float* ep_bias, const float* ep_add, float* ep_out2) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, 1, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2);
+}
+bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
+                                   int channels, int group_size, int hw) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
+	BLA_REQUIRE(d_in && d_relu && d_drop && d_dropped && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
 	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels,
-	                   group_size, hw);
+	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw,
+	                   d_drop, d_dropped);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
 
-}  // extern "C"
+bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
+                                int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
+	BLA_REQUIRE(d_source && d_dest && d_data && d_means && d_stdevs, BLA_ERR_INVALID, "null operand");
+	return launch_group_norm_ddx(pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels, group_size, hw, d_relu_gate, d_addend);
+}
+}  // namespace bla

@@ -211,20 +211,19 @@ bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d
 	BLA_REQUIRE(cin == cout || (p->res && ws->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and workspace");
 	const int hw = h * w;
 	st = bla_group_norm_relu_f32(stream, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw); if (st) return st;         // :1046-1047
-	st = bla_conv2d_forward_f32(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1); if (st) return st;             // :1048
+	// the time-embedding projection first, so that its per-channel add (:1053) rides in the store of the first convolution (:1048)
 	bla_gemm_epilogue ep = {};
 	ep.alpha = 1.f; ep.bias_col = p->time_b;
 	st = bla_gemm_f32(stream, 0, 0, 1, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st; // :1051-1052
-	st = bla_add_tile_columns_f32(stream, ws->c1, cout, hw, ws->tdense, 1); if (st) return st;                               // :1053
-	st = bla_group_norm_relu_f32(stream, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw); if (st) return st;      // :1056-1057
-	st = bla_dropout_f32(stream, ws->relu2, ws->dp, d_drop, (size_t)cout * hw); if (st) return st;                           // :1058
-	st = bla_conv2d_forward_f32(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1); if (st) return st;               // :1059
+	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr); if (st) return st;   // :1048,1053
+	st = group_norm_relu_dropout(stream, ws->c1, ws->relu2, d_drop, ws->dp, ws->sd2, ws->mu2, cout, group_size, hw); if (st) return st;   // :1056-1058, one pass
 	const float* r = d_x;
 	if (cin != cout) {
 		st = bla_conv2d_forward_f32(stream, d_x, p->res, ws->res, h, w, 1, cin, cout, 1); if (st) return st;                // :1062-1066
 		r = ws->res;
 	}
-	return bla_sum_f32(stream, d_result, ws->c2, r, (size_t)cout * hw);                                                      // :1067-1071
+	// second convolution (:1059) with the residual sum (:1067-1071) in its store: c2 = conv, result = c2 + r
+	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result);
 }
 
 bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
@@ -238,22 +237,22 @@ bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const f
 	const int hw = h * w;
 	// second chunk, :1186-1189
 	st = bla_conv2d_backward_f32(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, h, w, k, cout, cout, 1); if (st) return st;
-	st = bla_dropout_mask_f32(stream, sc->g_out_a, ws->dp, (size_t)cout * hw); if (st) return st;
-	st = bla_relu_mask_f32(stream, sc->g_out_a, sc->g_out_a, ws->relu2, (size_t)cout * hw); if (st) return st;
-	st = bla_group_norm_ddx_f32(stream, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw); if (st) return st;
+	// _dropout_mask then multi_channel_relu_ddx (:1187-1188) as the gate of the group-norm gradient: dp = drop ? 0 : relu2 is zero wherever
+	// relu2 is, so "dp <= 0" is both masks at once (dp >= 0 everywhere)
+	st = group_norm_ddx_gated(stream, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
 	// time-embedding projection, :1191-1199: bias gradient = per-channel sums, weight gradient = temb^T . dtb (rank 1)
 	st = bla_col_sum_f32(stream, sc->g_out_b, cout, hw, g->time_b, BLA_COLSUM_INTENDED); if (st) return st;
 	st = bla_gemm_f32(stream, 1, 0, tdim, cout, 1, d_temb, tdim, g->time_b, cout, g->time_w, cout, nullptr); if (st) return st;
 	// first chunk, :1202-1205 (gradient sink = the gradient struct; as written :1203 hands conv_ddx the parameters, Q8)
 	st = bla_conv2d_backward_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, sc->g_in, sc->flip, h, w, k, cin, cout, 1); if (st) return st;
-	st = bla_relu_mask_f32(stream, sc->g_in, sc->g_in, ws->relu1, (size_t)cin * hw); if (st) return st;
-	st = bla_group_norm_ddx_f32(stream, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw); if (st) return st;
-	// residual connection, :1208-1220
+	// ReLU gate on the way in (:1204); with an identity residual its gradient (del_out itself, :1219) is added on the way out
+	st = group_norm_ddx_gated(stream, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st;
+	// residual connection through the 1x1 convolution, :1208-1220
 	if (cin != cout) {
 		st = bla_conv2d_backward_f32(stream, d_del_out, d_x, p->res, g->res, sc->g_in, sc->flip, h, w, 1, cin, cout, 1); if (st) return st;
 		return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)cin * hw);
 	}
-	return bla_add_f32(stream, d_del_x, d_del_out, (size_t)cin * hw);
+	return BLA_OK;
 }
 
 }  // extern "C"

@@ -120,6 +120,24 @@ def test_group_norm(dev, ora):
     assert np.allclose(out.numpy(), g["probe_out"], rtol=1e-6)
 
 
+def test_group_norm_large_groups(dev, ora):
+    """Groups beyond the one-pass paths (32 channels x 32x32 = the U-Net's first level; a ragged last group; a group larger than
+    the forward kernel's register copy): the gradient is cut into slices over several workgroups there.  Against the fp64 oracle."""
+    for i, (c, gs, h, w) in enumerate([(64, 32, 32, 32), (40, 32, 32, 32), (48, 48, 32, 32), (3, 32, 128, 128)]):
+        x = uniform(2300 + i, (c, h, w), -1, 3, F32); up = uniform(2400 + i, (c, h, w), -1, 1, F32)
+        ng = (c + gs - 1) // gs
+        out, sd, mu, dest = dev.empty((c, h, w)), dev.empty((ng,)), dev.empty((ng,)), dev.empty((c, h, w)).fill_bytes(0xFF)
+        call(dev, "bla_group_norm_f32", dev.to_device(x), out, sd, mu, c, gs, h * w)
+        o64, sd64, mu64 = ora.group_norm(x.astype(np.float64), gs)
+        assert np.allclose(mu.numpy(), mu64, rtol=2e-6, atol=1e-7) and np.allclose(sd.numpy(), sd64, rtol=5e-6)
+        assert np.allclose(out.numpy(), o64, rtol=1e-5, atol=1e-6)
+        call(dev, "bla_group_norm_ddx_f32", dev.to_device(up), dest, dev.to_device(x), mu, sd, c, gs, h * w)
+        ref = ora.group_norm_ddx(up.astype(np.float64), x.astype(np.float64), mu64, sd64, gs)
+        got = dest.numpy()
+        assert np.isfinite(got).all()
+        assert (np.abs(got - ref) <= 2e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max()).all()
+
+
 def test_implicit_gemm_conv_matches_reference(dev, ora):
     """bla_conv2d_forward/backward (im2col gathered inside the MFMA kernel, nothing materialised) against the same
     golden vectors as the staged path: conv()'s output for every stride, conv_ddx()'s del_kernels / del_input at stride 1,
