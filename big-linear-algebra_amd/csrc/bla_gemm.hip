@@ -1662,14 +1662,20 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 	hipStream_t s = pick_stream(stream);
 	const int tp = pp.valid ? pp.a.tiles_m * pp.a.tiles_n : 0, tq = pq.valid ? pq.a.tiles_m * pq.a.tiles_n : 0;
 	hipError_t e = hipSuccess;
-	if (pp.valid && pq.valid && pp.akc && pp.bkc && !pq.akc && !pq.bkc && !pp.a.softmax_grad && !pq.a.softmax_grad) {   // NT beside TN (dW_l beside dZ_{l-1})
-		hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<true, true, false, false>), dim3((unsigned)(tp + tq)), dim3(256), 0, s, pp.a, pq.a, tp);
+	if (pp.valid && pq.valid && !pp.a.softmax_grad && !pq.a.softmax_grad) {
+		// every layout combination has its instantiation (NT beside TN = dW_l beside dZ_{l-1}, NT beside NT = two weight gradients,
+		// TN beside TN = the attention block's Q and K projections, ...)
+		const dim3 grid((unsigned)(tp + tq));
+		const int combo = (pp.akc ? 8 : 0) | (pp.bkc ? 4 : 0) | (pq.akc ? 2 : 0) | (pq.bkc ? 1 : 0);
+#define BLA_PAIR_CASE(I) case I: hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<((I) & 8) != 0, ((I) & 4) != 0, ((I) & 2) != 0, ((I) & 1) != 0>), grid, dim3(256), 0, s, pp.a, pq.a, tp); break
+		switch (combo) {
+			BLA_PAIR_CASE(0); BLA_PAIR_CASE(1); BLA_PAIR_CASE(2); BLA_PAIR_CASE(3); BLA_PAIR_CASE(4); BLA_PAIR_CASE(5); BLA_PAIR_CASE(6); BLA_PAIR_CASE(7);
+			BLA_PAIR_CASE(8); BLA_PAIR_CASE(9); BLA_PAIR_CASE(10); BLA_PAIR_CASE(11); BLA_PAIR_CASE(12); BLA_PAIR_CASE(13); BLA_PAIR_CASE(14); BLA_PAIR_CASE(15);
+		}
+#undef BLA_PAIR_CASE
 		e = hipGetLastError();
-		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_nt+tn_%d+%d", tp, tq);
-	} else if (pp.valid && pq.valid && pp.akc && pp.bkc && pq.akc && pq.bkc && !pp.a.softmax_grad && !pq.a.softmax_grad) {   // NT beside NT (two weight-gradient products)
-		hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<true, true, true, true>), dim3((unsigned)(tp + tq)), dim3(256), 0, s, pp.a, pq.a, tp);
-		e = hipGetLastError();
-		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_nt+nt_%d+%d", tp, tq);
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_%c%c+%c%c_%d+%d", pp.akc ? 'n' : 't', pp.bkc ? 't' : 'n', pq.akc ? 'n' : 't',
+		         pq.bkc ? 't' : 'n', tp, tq);
 	} else {
 		if (pp.valid) e = launch_wsk(pp.a, pp.akc, pp.bkc, true, true, dim3((unsigned)tp, 1), s);
 		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);

@@ -149,6 +149,16 @@ static bla_status ep_gemm(void* s, int ta, int tb, int m, int n, int k, const fl
 	return bla_gemm_f32(s, ta, tb, m, n, k, A, lda, B, ldb, C, ldc, &ep);
 }
 
+// two independent products in one launch where both are latency-bound shapes (bla_gemm_pair_f32); plain alpha/beta epilogues
+static bla_status pair_gemm(void* s, int ta1, int tb1, int m1, int n1, int k1, const float* A1, int lda1, const float* B1, int ldb1, float* C1, int ldc1,
+                            int ta2, int tb2, int m2, int n2, int k2, const float* A2, int lda2, const float* B2, int ldb2, float* C2, int ldc2, float alpha2 = 1.f) {
+	bla_gemm_epilogue e1 = {}, e2 = {};
+	e1.alpha = 1.f; e2.alpha = alpha2;
+	bla_gemm_desc p = {ta1, tb1, m1, n1, k1, A1, lda1, B1, ldb1, C1, ldc1, &e1};
+	bla_gemm_desc q = {ta2, tb2, m2, n2, k2, A2, lda2, B2, ldb2, C2, ldc2, &e2};
+	return bla_gemm_pair_f32(s, &p, &q);
+}
+
 bla_status bla_attention_forward_f32(void* stream, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv, const float* d_w,
                                      const float* d_bias, const bla_attention_ws* ws, float* d_out, int c, int s, int d) {
 	BLA_ENTER();
@@ -156,11 +166,14 @@ bla_status bla_attention_forward_f32(void* stream, const float* d_x, const float
 	BLA_REQUIRE(d_x && d_wq && d_wk && d_wv && d_w && d_bias && d_out && ws && ws->q && ws->k && ws->v && ws->scores_raw && ws->weights && ws->attention,
 	            BLA_ERR_INVALID, "null operand");
 	const float inv = (float)(1.0 / sqrt((double)d));                                                  // :1010
-	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wq, d, ws->q, d, 1.f, 0.f, nullptr); if (st) return st;   // Q = Z Wq, Z = X^T   :1003-1004
-	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wk, d, ws->k, d, 1.f, 0.f, nullptr); if (st) return st;
+	st = pair_gemm(stream, 1, 0, s, d, c, d_x, s, d_wq, d, ws->q, d,                                       // Q = Z Wq, Z = X^T   :1003-1004
+	               1, 0, s, d, c, d_x, s, d_wk, d, ws->k, d); if (st) return st;                          // beside K = Z Wk (one launch)
 	st = ep_gemm(stream, 1, 0, s, d, c, d_x, s, d_wv, d, ws->v, d, 1.f, 0.f, nullptr); if (st) return st;
-	st = ep_gemm(stream, 0, 1, s, s, d, ws->q, d, ws->k, d, ws->scores_raw, s, inv, 0.f, nullptr); if (st) return st;   // (Q K^T) / sqrt(d)   :1007-1014
-	st = bla_memcpy_d2d(ws->weights, ws->scores_raw, (size_t)s * s * sizeof(float), stream); if (st) return st;
+	{   // (Q K^T) / sqrt(d) :1007-1014, stored twice by the product itself: scores_raw (kept) and weights (softmaxed in place, :1015)
+		bla_gemm_epilogue ep = {};
+		ep.alpha = inv; ep.pre_act = ws->scores_raw; ep.ld_pre = s;
+		st = bla_gemm_f32(stream, 0, 1, s, s, d, ws->q, d, ws->k, d, ws->weights, s, &ep); if (st) return st;
+	}
 	st = bla_softmax_rows_f32(stream, ws->weights, s, s); if (st) return st;                               // :1015
 	st = ep_gemm(stream, 0, 0, s, d, s, ws->weights, s, ws->v, d, ws->attention, d, 1.f, 0.f, nullptr); if (st) return st;   // :1018
 	return ep_gemm(stream, 1, 1, c, s, d, d_w, c, ws->attention, d, d_out, s, 1.f, 0.f, d_bias);              // (P W + b)^T   :1019-1021
@@ -175,18 +188,19 @@ bla_status bla_attention_backward_f32(void* stream, const float* d_del_y, const 
 	BLA_REQUIRE(g->q && g->k && g->v && g->scores_raw && g->weights && g->attention, BLA_ERR_INVALID, "null gradient workspace");
 	const float inv = (float)(1.0 / sqrt((double)d));
 	float *del_q = g->q, *del_k = g->k, *del_v = g->v, *del_i = g->scores_raw, *del_s = g->weights, *del_p = g->attention;
-	st = ep_gemm(stream, 1, 1, d, c, s, fw->attention, d, d_del_y, s, d_del_w, c, 1.f, 0.f, nullptr); if (st) return st;   // del_W = P^T del_Y'     :1291-1293
-	st = ep_gemm(stream, 1, 1, s, d, c, d_del_y, s, d_w, c, del_p, d, 1.f, 0.f, nullptr); if (st) return st;               // del_P = del_Y' W^T     :1295-1297
-	st = ep_gemm(stream, 1, 0, s, d, s, fw->weights, s, del_p, d, del_v, d, 1.f, 0.f, nullptr); if (st) return st;         // del_V = S^T del_P      :1299-1301
-	st = ep_gemm(stream, 0, 1, s, s, d, del_p, d, fw->v, d, del_s, s, 1.f, 0.f, nullptr); if (st) return st;               // del_S = del_P V^T      :1303-1305
+	// independent products share a launch (the reference runs all fourteen one after the other)
+	st = pair_gemm(stream, 1, 1, d, c, s, fw->attention, d, d_del_y, s, d_del_w, c,                                          // del_W = P^T del_Y'     :1291-1293
+	               1, 1, s, d, c, d_del_y, s, d_w, c, del_p, d); if (st) return st;                                         // del_P = del_Y' W^T     :1295-1297
+	st = pair_gemm(stream, 0, 1, s, s, d, del_p, d, fw->v, d, del_s, s,                                                     // del_S = del_P V^T      :1303-1305
+	               1, 0, s, d, s, fw->weights, s, del_p, d, del_v, d); if (st) return st;                                   // del_V = S^T del_P      :1299-1301
 	st = bla_softmax_ddx_f32(stream, jacobian_from_raw ? fw->scores_raw : fw->weights, del_s, del_i, s, s); if (st) return st;   // :1307
 	st = bla_scale_f32(stream, del_i, (size_t)s * s, inv); if (st) return st;                                                // :1308
-	st = ep_gemm(stream, 0, 0, s, d, s, del_i, s, fw->k, d, del_q, d, 1.f, 0.f, nullptr); if (st) return st;               // :1310
-	st = ep_gemm(stream, 1, 0, s, d, s, del_i, s, fw->q, d, del_k, d, 1.f, 0.f, nullptr); if (st) return st;               // :1312-1314
-	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_k, d, d_del_wk, d, 1.f, 0.f, nullptr); if (st) return st;              // Z^T = X              :1316-1319
-	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_q, d, d_del_wq, d, 1.f, 0.f, nullptr); if (st) return st;
-	st = ep_gemm(stream, 0, 0, c, d, s, d_x, s, del_v, d, d_del_wv, d, 1.f, 0.f, nullptr); if (st) return st;
-	st = ep_gemm(stream, 0, 1, c, s, d, d_wq, d, del_q, d, d_del_x, s, 1.f, 0.f, nullptr); if (st) return st;              // del_Z^T, same add order :1322-1334
+	st = pair_gemm(stream, 0, 0, s, d, s, del_i, s, fw->k, d, del_q, d,                                                     // :1310
+	               1, 0, s, d, s, del_i, s, fw->q, d, del_k, d); if (st) return st;                                         // :1312-1314
+	st = pair_gemm(stream, 0, 0, c, d, s, d_x, s, del_k, d, d_del_wk, d,                                                    // Z^T = X              :1316-1319
+	               0, 0, c, d, s, d_x, s, del_q, d, d_del_wq, d); if (st) return st;
+	st = pair_gemm(stream, 0, 0, c, d, s, d_x, s, del_v, d, d_del_wv, d,
+	               0, 1, c, s, d, d_wq, d, del_q, d, d_del_x, s); if (st) return st;                                        // del_Z^T, same add order :1322-1334
 	st = ep_gemm(stream, 0, 1, c, s, d, d_wk, d, del_k, d, d_del_x, s, 1.f, 1.f, nullptr); if (st) return st;
 	return ep_gemm(stream, 0, 1, c, s, d, d_wv, d, del_v, d, d_del_x, s, 1.f, 1.f, nullptr);
 }

@@ -267,7 +267,8 @@ def test_wave_split_k_with_in_launch_fold(dev, ora, split):
 
 def test_gemm_pair_shares_one_launch(dev, ora):
     """bla_gemm_pair_f32: an NT product beside a TN product (dW_l beside dZ_{l-1} of model/mnist_nn.c:267-289) in one launch,
-    both with their epilogues (row sums of A / relu' mask); other combinations fall back to two launches.  Same results either way."""
+    both with their epilogues (row sums of A / relu' mask); products that do not fit the latency-bound kernel fall back to two launches.
+    Same results either way."""
     nat = dev.native
     for (m1, n1, k1, m2, n2, k2) in [(10, 128, 256, 128, 256, 10), (128, 256, 256, 256, 256, 128), (33, 40, 64, 70, 36, 33)]:
         a1 = uniform(1, (m1, k1), dtype=np.float32); b1 = uniform(2, (n1, k1), dtype=np.float32)      # NT: A [m][k], B [n][k]
@@ -292,6 +293,29 @@ def test_gemm_pair_shares_one_launch(dev, ora):
     c1, c2 = dev.zeros((128, 256)), dev.zeros((256, 256))
     nat.gemm_pair(nat.gemm_desc(a1, b1, c1, transb=True), nat.gemm_desc(a2, b2, c2, transa=True))
     assert "pair_nt+tn" in dev.lib().bla_gemm_last_kernel().decode()
+
+
+def test_gemm_pair_every_layout_combination(dev, ora):
+    """All 16 (op(A), op(B)) x (op(A), op(B)) combinations of two latency-bound products share one launch (the attention block of
+    model/cifar_unet.c:999-1022,1261-1337 pairs TN+TN, TT+TT, NN+TN, NN+NN, NN+NT ...) and give bit-for-bit what two separate calls give."""
+    nat = dev.native
+    m1, n1, k1, m2, n2, k2 = 64, 96, 128, 160, 32, 64
+    for ta1 in (False, True):
+        for tb1 in (False, True):
+            for ta2 in (False, True):
+                for tb2 in (False, True):
+                    a1 = uniform(11, (k1, m1) if ta1 else (m1, k1), dtype=np.float32); b1 = uniform(12, (n1, k1) if tb1 else (k1, n1), dtype=np.float32)
+                    a2 = uniform(13, (k2, m2) if ta2 else (m2, k2), dtype=np.float32); b2 = uniform(14, (n2, k2) if tb2 else (k2, n2), dtype=np.float32)
+                    d = [dev.to_device(x) for x in (a1, b1, a2, b2)]
+                    c1, c2, s1, s2 = dev.zeros((m1, n1)), dev.zeros((m2, n2)), dev.zeros((m1, n1)), dev.zeros((m2, n2))
+                    nat.gemm_pair(nat.gemm_desc(d[0], d[1], c1, transa=ta1, transb=tb1), nat.gemm_desc(d[2], d[3], c2, transa=ta2, transb=tb2))
+                    name = dev.lib().bla_gemm_last_kernel().decode()
+                    want = "pair_" + ("t" if ta1 else "n") + ("t" if tb1 else "n") + "+" + ("t" if ta2 else "n") + ("t" if tb2 else "n")
+                    assert want in name, (want, name)
+                    dev.gemm(d[0], d[1], s1, transa=ta1, transb=tb1); dev.gemm(d[2], d[3], s2, transa=ta2, transb=tb2)
+                    assert np.array_equal(c1.numpy(), s1.numpy()) and np.array_equal(c2.numpy(), s2.numpy()), name
+                    check_gemm(ora, c1.numpy(), a1.T if ta1 else a1, b1.T if tb1 else b1, tag=name)
+                    check_gemm(ora, c2.numpy(), a2.T if ta2 else a2, b2.T if tb2 else b2, tag=name)
 
 
 def test_recorded_sequence_replays_on_new_data(dev, ora):
