@@ -198,6 +198,51 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_ddx_kernel(const float*
 // partials in slice order (identical totals everywhere, deterministic) and writes its part.  Same gate / addend options as the kernel above.
 constexpr int kGnSlice = 2048, kGnSliceThreads = 256;
 
+// forward pass of a large group, same slicing: partial sum x and sum x^2 in fp64 (x^2 is exact in fp64), then every slice forms
+//   mean = (float)(sum x / n)   and   variance about that float mean = (sum x^2 - 2 mean sum x + n mean^2) / n
+// -- the two passes of lib/norm.c:26-37 from one pass over memory -- and normalises its part.
+__global__ void __launch_bounds__(kGnSliceThreads) group_norm_stats_kernel(const float* __restrict__ in, int channels, int group_size, int hw, double2* partials) {
+	const int g = blockIdx.y, slice = blockIdx.x;
+	const int nch = min(group_size, channels - g * group_size);
+	const size_t off = (size_t)g * group_size * hw;
+	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
+	double a = 0, b = 0;
+	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) { double x = in[off + i]; a += x; b += x * x; }
+	__shared__ double sh[2][kGnSliceThreads / 64];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double ta = 0, tb = 0;
+		for (int i = 0; i < kGnSliceThreads / 64; i++) { ta += sh[0][i]; tb += sh[1][i]; }
+		partials[(size_t)g * gridDim.x + slice] = make_double2(ta, tb);
+	}
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
+                                                                            float* __restrict__ means, int channels, int group_size, int hw,
+                                                                            const unsigned char* __restrict__ drop, float* __restrict__ dropped,
+                                                                            const double2* __restrict__ partials) {
+	const int g = blockIdx.y, slice = blockIdx.x;
+	const int nch = min(group_size, channels - g * group_size);
+	const size_t off = (size_t)g * group_size * hw;
+	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
+	double a = 0, b = 0;
+	for (unsigned i = 0; i < gridDim.x; i++) { double2 q = partials[(size_t)g * gridDim.x + i]; a += q.x; b += q.y; }   // slice order: same totals everywhere
+	const float mean = (float)(a / (double)n);
+	const double m = (double)mean;
+	const float var = (float)((b - 2.0 * m * a + (double)n * m * m) / (double)n);
+	if (slice == 0 && threadIdx.x == 0) { means[g] = mean; stdevs[g] = var; }
+	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
+		float y = (in[off + i] - mean) / var;
+		y = RELU && y < 0.f ? 0.f : y;
+		out[off + i] = y;
+		if (dropped) dropped[off + i] = drop[off + i] ? 0.f : y;
+	}
+}
+
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_stats_kernel(const float* __restrict__ source, const float* __restrict__ data,
                                                                                 const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
                                                                                 int group_size, int hw, const float* __restrict__ relu_gate, double2* partials) {
@@ -675,6 +720,27 @@ static bla_status launch_backward_pair(hipStream_t s, ConvArgs& w, ConvArgs& d, 
 	return BLA_OK;
 }
 
+template <bool RELU>
+static bla_status launch_group_norm(hipStream_t s, const float* in, float* out, float* stdevs, float* means, int channels, int group_size, int hw,
+                                    const unsigned char* drop, float* dropped) {
+	const int groups = (channels + group_size - 1) / group_size;
+	const long n_max = (long)(channels < group_size ? channels : group_size) * hw;
+	if (n_max <= kGnThreads * (kGnRegs / 2)) {   // (the one-workgroup kernel holds up to twice that in registers, but at 12 us against 9 sliced)
+		hipLaunchKernelGGL(group_norm_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped);
+	} else {
+		const unsigned slices = (unsigned)((n_max + kGnSlice - 1) / kGnSlice);
+		BLA_REQUIRE(groups <= 65535, BLA_ERR_INVALID, "too many groups (%d)", groups);
+		void* ws;
+		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
+		if (st) return st;
+		hipLaunchKernelGGL(group_norm_stats_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
+		hipLaunchKernelGGL(group_norm_apply_kernel<RELU>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
+		                   dropped, (const double2*)ws);
+	}
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 static bla_status launch_group_norm_ddx(hipStream_t s, const float* source, float* dest, const float* data, const float* means, const float* stdevs, int channels,
                                         int group_size, int hw, const float* relu_gate, const float* addend) {
 	const int groups = (channels + group_size - 1) / group_size;
@@ -929,11 +995,7 @@ bla_status bla_group_norm_f32(void* stream, const float* d_in, float* d_out, flo
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
-	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel<false>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw,
-	                   (const unsigned char*)nullptr, (float*)nullptr);
-	BLA_HIP(hipGetLastError());
-	return BLA_OK;
+	return launch_group_norm<false>(pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw, nullptr, nullptr);
 }
 
 bla_status bla_group_norm_relu_f32(void* stream, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw) {
@@ -941,11 +1003,7 @@ bla_status bla_group_norm_relu_f32(void* stream, const float* d_in, float* d_out
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_out && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
-	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw,
-	                   (const unsigned char*)nullptr, (float*)nullptr);
-	BLA_HIP(hipGetLastError());
-	return BLA_OK;
+	return launch_group_norm<true>(pick_stream(stream), d_in, d_out, d_stdevs, d_means, channels, group_size, hw, nullptr, nullptr);
 }
 
 bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
@@ -970,11 +1028,7 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_in && d_relu && d_drop && d_dropped && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
-	int groups = (channels + group_size - 1) / group_size;
-	hipLaunchKernelGGL(group_norm_kernel<true>, dim3(groups), dim3(kGnThreads), 0, pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw,
-	                   d_drop, d_dropped);
-	BLA_HIP(hipGetLastError());
-	return BLA_OK;
+	return launch_group_norm<true>(pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw, d_drop, d_dropped);
 }
 
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
