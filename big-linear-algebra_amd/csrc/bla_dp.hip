@@ -79,8 +79,8 @@ __device__ __forceinline__ void deliver(const DpKernelArgs& a, unsigned i, float
 }
 
 // wait until flags[r] has reached `epoch` for every r < world (threads r < world poll); returns false on time-out
-__device__ __forceinline__ bool wait_flags(const unsigned* flags, int world, unsigned epoch, int* s_fail) {
-	if ((int)threadIdx.x < world) {
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int world, int rank, unsigned epoch, int* s_fail) {
+	if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {   // (a rank's own data is ordered by its stream: no flag to itself)
 		const long long t0 = wall_clock64();
 		while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
 			__builtin_amdgcn_s_sleep(4);
@@ -97,11 +97,9 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 	const unsigned epoch = a.state[0] + 1;
 	if (threadIdx.x == 0) { s_fail = 0; s_last = 0; }
 	__syncthreads();
-	if (blockIdx.x == 0 && (int)threadIdx.x < a.world) {
-		__threadfence_system();
+	if (blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)   // (the system-scope release is the fence)
 		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	bool ok = wait_flags(a.flags, a.world, epoch, &s_fail);
+	bool ok = wait_flags(a.flags, a.world, a.rank, epoch, &s_fail);
 	// phase A: my slice of every bucket, summed in rank order -> reduced buffer (for the peers) and my own out / target
 	const unsigned lo = a.rank * a.per4, hi = min(lo + a.per4, a.n4);
 	if (ok) {
@@ -123,19 +121,17 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		__threadfence_system();
+		if (lo + blockIdx.x * 256 < hi) __threadfence_system();   // only a workgroup that wrote part of the reduced slice has something to publish
 		s_last = atomicAdd(a.state + 3, 1u) == gridDim.x - 1;
 	}
 	__syncthreads();
 	if (s_last) {
 		if (threadIdx.x == 0) a.state[3] = 0;
-		if ((int)threadIdx.x < a.world) {
-			__threadfence_system();
+		if ((int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)
 			__hip_atomic_store(a.peer_flags_b[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
 	}
 	// phase B: the peers' reduced slices
-	ok = wait_flags(a.flags_b, a.world, epoch, &s_fail) && ok;
+	ok = wait_flags(a.flags_b, a.world, a.rank, epoch, &s_fail) && ok;
 	if (ok) {
 		const unsigned rest = a.n4 - (hi - lo);   // groups owned by the peers
 		for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < rest; j += gridDim.x * 256) {
@@ -147,10 +143,11 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (s_fail) atomicOr(a.state + 2, 1u);
-		__threadfence();
+		// No fence: every workgroup consumed state[0] (its epoch) long before its own arrival, so the last arriver's store cannot be seen by
+		// a read of this launch; the next launch is ordered by the stream.
 		if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {
 			a.state[1] = 0;
-			__hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }
@@ -160,11 +157,10 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 	const unsigned epoch = a.state[0] + 1;   // bumped by the last workgroup of this launch, after every workgroup has read it
 	if (threadIdx.x == 0) s_fail = 0;
 	__syncthreads();
-	if (blockIdx.x == 0 && threadIdx.x < a.world) {
-		__threadfence_system();   // this rank's gradient kernels finished before this launch; make their bytes visible to the peers
+	// this rank's gradient kernels finished before this launch; the system-scope release makes their bytes visible to the peers
+	if (blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)
 		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	if (threadIdx.x < a.world) {
+	if ((int)threadIdx.x < a.world && (int)threadIdx.x != a.rank) {   // (a rank's own data is ordered by its stream: no flag to itself)
 		const long long t0 = wall_clock64();
 		while ((int)(__hip_atomic_load(a.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
 			__builtin_amdgcn_s_sleep(4);
@@ -209,10 +205,9 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (fail) atomicOr(a.state + 2, 1u);
-		__threadfence();
-		if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {   // last workgroup: every workgroup has read state[0] and finished its reads
+		if (atomicAdd(a.state + 1, 1u) == gridDim.x - 1) {   // last workgroup: every workgroup has read state[0] (no fence needed, see above)
 			a.state[1] = 0;
-			__hip_atomic_store(a.state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }
