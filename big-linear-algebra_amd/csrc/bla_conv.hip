@@ -15,6 +15,8 @@
 //     around its two products (lib/conv.c:221-227) disappear into the GEMM's transa/transb.
 #include "bla_internal.h"
 #include <cmath>
+#include <mutex>
+#include <vector>
 
 namespace bla {
 
@@ -495,23 +497,41 @@ __global__ void __launch_bounds__(kThreads) flip_kernels_kernel(const float* __r
 	}
 }
 
-// per-geometry gather tables, built once (device memory is never freed: a handful of KB per distinct layer shape)
-struct TableEntry { ConvGeom g; int2* tab; };
-static TableEntry g_tables[64];
-static int g_num_tables = 0;
+// Per-geometry gather tables, built once per device (device memory is never freed: a handful of KB per distinct layer shape).
+// The caches are process-wide: guarded by one mutex, keyed by device.  A table is filled on the library's own stream and waited for
+// BEFORE its cache entry is published, so a second caller on another stream never sees a half-built table; and a first use while the
+// caller's stream is recording a graph is refused (allocating is not allowed there, and the fill would only run at replay time):
+// run a sequence once eagerly before recording it (include/bla.h, bla_graph_begin).
+static std::mutex g_table_mu;
+static bla_status table_build_allowed(hipStream_t s) {
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+		set_error("first use of a convolution geometry while the stream is recording a graph: run the sequence once eagerly before bla_graph_begin");
+		return BLA_ERR_INVALID;
+	}
+	(void)hipGetLastError();
+	return BLA_OK;
+}
+
+struct TableEntry { int device; ConvGeom g; int2* tab; };
+static std::vector<TableEntry> g_tables;
 
 static bla_status get_table(hipStream_t s, const ConvGeom& g, const int2** out) {
-	for (int i = 0; i < g_num_tables; i++) {
-		const ConvGeom& t = g_tables[i].g;
-		if (t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c && t.s == g.s && t.pt == g.pt && t.pl == g.pl) { *out = g_tables[i].tab; return BLA_OK; }
+	std::lock_guard<std::mutex> lk(g_table_mu);
+	const int dev = ctx().device;
+	for (const TableEntry& e : g_tables) {
+		const ConvGeom& t = e.g;
+		if (e.device == dev && t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c && t.s == g.s && t.pt == g.pt && t.pl == g.pl) { *out = e.tab; return BLA_OK; }
 	}
-	BLA_REQUIRE(g_num_tables < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	bla_status st = table_build_allowed(s);
+	if (st) return st;
 	int n = g.c * g.k * g.k;
 	int2* tab;
 	BLA_HIP(hipMalloc((void**)&tab, (size_t)n * sizeof(int2)));
-	hipLaunchKernelGGL(conv_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, g);
+	hipLaunchKernelGGL(conv_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx().stream, tab, g);
 	BLA_HIP(hipGetLastError());
-	g_tables[g_num_tables].g = g; g_tables[g_num_tables].tab = tab; g_num_tables++;
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
+	g_tables.push_back(TableEntry{dev, g, tab});
 	*out = tab;
 	return BLA_OK;
 }
@@ -524,22 +544,23 @@ __global__ void __launch_bounds__(256) conv_pixel_table_kernel(int2* tab, ConvGe
 	tab[r] = make_int2(i * g.s * g.w + j * g.s, ((i * g.s) & 0xffff) | ((j * g.s) << 16));
 }
 
-struct PixelTableEntry { int w, s, ho, wo; int2* tab; };
-static PixelTableEntry g_ptables[64];
-static int g_num_ptables = 0;
+struct PixelTableEntry { int device, w, s, ho, wo; int2* tab; };
+static std::vector<PixelTableEntry> g_ptables;
 
 static bla_status get_pixel_table(hipStream_t s, const ConvGeom& g, const int2** out) {
-	for (int i = 0; i < g_num_ptables; i++) {
-		const PixelTableEntry& t = g_ptables[i];
-		if (t.w == g.w && t.s == g.s && t.ho == g.ho && t.wo == g.wo) { *out = t.tab; return BLA_OK; }
-	}
-	BLA_REQUIRE(g_num_ptables < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	std::lock_guard<std::mutex> lk(g_table_mu);
+	const int dev = ctx().device;
+	for (const PixelTableEntry& t : g_ptables)
+		if (t.device == dev && t.w == g.w && t.s == g.s && t.ho == g.ho && t.wo == g.wo) { *out = t.tab; return BLA_OK; }
+	bla_status st = table_build_allowed(s);
+	if (st) return st;
 	int n = g.ho * g.wo;
 	int2* tab;
 	BLA_HIP(hipMalloc((void**)&tab, (size_t)n * sizeof(int2)));
-	hipLaunchKernelGGL(conv_pixel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, g);
+	hipLaunchKernelGGL(conv_pixel_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx().stream, tab, g);
 	BLA_HIP(hipGetLastError());
-	g_ptables[g_num_ptables++] = PixelTableEntry{g.w, g.s, g.ho, g.wo, tab};
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
+	g_ptables.push_back(PixelTableEntry{dev, g.w, g.s, g.ho, g.wo, tab});
 	*out = tab;
 	return BLA_OK;
 }
@@ -563,24 +584,27 @@ __global__ void __launch_bounds__(256) padded_tables_kernel(int2* taps, int2* pi
 	if (e < c_n * kk) { int c = e / kk, p = (e % kk) / k, q = e % k; taps[e] = make_int2(c * hp * wp + p * wp + q, 0); }
 	if (e < ho * wo) { int i = e / wo, j = e - i * wo; pix[e] = make_int2(i * wp + j, 0); }
 }
-struct PaddedTables { ConvGeom g; int2* taps; int2* pix; };
-static PaddedTables g_padded[64];
-static int g_num_padded = 0;
+struct PaddedTables { int device; ConvGeom g; int2* taps; int2* pix; };
+static std::vector<PaddedTables> g_padded;
 
 static bla_status get_padded_tables(hipStream_t s, const ConvGeom& g, const int2** taps, const int2** pix) {
-	for (int i = 0; i < g_num_padded; i++) {
-		const ConvGeom& t = g_padded[i].g;
-		if (t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c) { *taps = g_padded[i].taps; *pix = g_padded[i].pix; return BLA_OK; }
+	std::lock_guard<std::mutex> lk(g_table_mu);
+	const int dev = ctx().device;
+	for (const PaddedTables& e : g_padded) {
+		const ConvGeom& t = e.g;
+		if (e.device == dev && t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c) { *taps = e.taps; *pix = e.pix; return BLA_OK; }
 	}
-	BLA_REQUIRE(g_num_padded < 64, BLA_ERR_INVALID, "more than 64 distinct convolution geometries in one process");
+	bla_status st = table_build_allowed(s);
+	if (st) return st;
 	int nt = g.c * g.k * g.k, np = g.ho * g.wo;
 	int2 *t, *q;
 	BLA_HIP(hipMalloc((void**)&t, (size_t)nt * sizeof(int2)));
 	BLA_HIP(hipMalloc((void**)&q, (size_t)np * sizeof(int2)));
 	int n = nt > np ? nt : np;
-	hipLaunchKernelGGL(padded_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, q, g.c, g.k, g.h + g.k - 1, g.w + g.k - 1, g.ho, g.wo);
+	hipLaunchKernelGGL(padded_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx().stream, t, q, g.c, g.k, g.h + g.k - 1, g.w + g.k - 1, g.ho, g.wo);
 	BLA_HIP(hipGetLastError());
-	g_padded[g_num_padded++] = PaddedTables{g, t, q};
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
+	g_padded.push_back(PaddedTables{dev, g, t, q});
 	*taps = t; *pix = q;
 	return BLA_OK;
 }

@@ -22,12 +22,15 @@
 // All ranks end up with the owner's sums, so the result is bit-identical to the one-shot form.  The second phase waits on
 // workgroups of the same launch on other GPUs, so that launch is kept small enough (128 workgroups) to be fully resident.
 //
-// Shared memory is fine-grained (uncached in L2, coherent at system scope) and
-// exported / opened with hipIpc*MemHandle, one process per GPU.  A wait that exceeds the time-out raises the
+// Buckets and reduced slices are fine-grained device memory, the flag words a separate uncached allocation; both are exported /
+// opened with hipIpc*MemHandle between processes and addressed directly between ranks of one process.  A wait that exceeds the time-out raises the
 // status word instead of spinning forever.
 #include "bla_internal.h"
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <random>
+#include <unistd.h>
 
 using namespace bla;
 
@@ -116,13 +119,21 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 			deliver(a, i, s);
 		}
 	}
-	// the workgroup that leaves phase A last publishes "my reduced slice is ready" to every peer (every wave first waits for its own
-	// stores to be acknowledged: the barrier alone does not, and lane 0's fence below only covers its own wave's queue)
+	// The workgroup that leaves phase A last publishes "my reduced slice is ready" to every peer.  Ordering:
+	//   writer workgroup w : stores to red_self -> every wave s_waitcnt vmcnt(0) (its stores are acknowledged by w's L2; the barrier
+	//                        alone does not wait for them, and lane 0's fence only covers its own wave's queue) -> barrier ->
+	//                        lane 0: system-scope RELEASE fence (writes w's XCD-private L2 back: the peers read over xGMI from memory,
+	//                        they do not snoop any L2 -- so every writing workgroup needs its own, the last arriver's would only
+	//                        clean the last arriver's L2) -> arrival RMW
+	//   last arriver       : arrival RMW with ACQUIRE: it reads the end of the RMW chain, which continues every writer's release
+	//                        sequence, so all writers' fences synchronise with it -> system-scope RELEASE store of flag B
+	//   peer               : system-scope ACQUIRE load of flag B -> barrier -> loads of red[]
+	// A workgroup that wrote nothing has nothing to publish and skips the fence (it still takes part in the count).
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		if (lo + blockIdx.x * 256 < hi) __threadfence_system();   // only a workgroup that wrote part of the reduced slice has something to publish
-		s_last = atomicAdd(a.state + 3, 1u) == gridDim.x - 1;
+		if (lo + blockIdx.x * 256 < hi) __threadfence_system();
+		s_last = __hip_atomic_fetch_add(a.state + 3, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
 	}
 	__syncthreads();
 	if (s_last) {
@@ -214,16 +225,39 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 }  // namespace
 
 struct bla_dp {
-	int rank, world;
+	unsigned long long id;       // never reused (an address can be)
+	int rank, world, device;
 	size_t count, padded;        // floats; padded to a multiple of 1024
-	char* base; size_t bytes;    // own fine-grained allocation: [bucket 0][bucket 1][reduced 0][reduced 1][flags A][flags B]
-	size_t red_off, flags_off;
+	char* base; size_t bytes;    // own fine-grained allocation: [bucket 0][bucket 1][reduced 0][reduced 1]
+	char* flags;                 // own flag words, a separate UNCACHED allocation: [flags A: 2048 B][flags B: 2048 B].  The peers write
+	                             // them over xGMI straight into this GPU's memory while this GPU polls them: they must never sit in its L2
+	bool flags_uncached;
+	size_t red_off;
 	unsigned per4;               // float4 groups per slice of the two-shot form
 	bool twoshot;
 	unsigned* state;             // local (ordinary device memory)
-	void* peer[kMaxWorld];       // opened peer allocations (own slot = base)
+	void* peer[kMaxWorld];       // peer data allocations (own slot = base): IPC mappings, or plain pointers for ranks of this process
+	void* peer_flags[kMaxWorld];
+	bool peer_ipc[kMaxWorld];    // opened through hipIpcOpenMemHandle (to be closed)
 	bool connected;
 };
+
+// What one rank tells the others (BLA_DP_HANDLE_BYTES opaque bytes): IPC handles for other processes, plain pointers for ranks that
+// live in the same process (hipIpcOpenMemHandle refuses a handle of the opening process itself).
+struct DpHandle {
+	hipIpcMemHandle_t data, flags;
+	unsigned long long pid, nonce;   // same process <=> both equal
+	unsigned long long base, flags_base;
+	int device;
+	unsigned magic;
+};
+static_assert(sizeof(DpHandle) <= BLA_DP_HANDLE_BYTES, "handle blob too small");
+static unsigned long long process_nonce() {
+	static const unsigned long long n = ((unsigned long long)std::random_device{}() << 32) ^ std::random_device{}() ^ (unsigned long long)(uintptr_t)&kMaxWorld;
+	return n;
+}
+static std::atomic<unsigned long long> g_next_dp_id{1};
+namespace bla { unsigned long long dp_identity(const bla_dp* dp) { return dp ? dp->id : 0; } }
 
 extern "C" {
 
@@ -233,29 +267,30 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	BLA_REQUIRE(out && count > 0 && count < ((size_t)1 << 31), BLA_ERR_INVALID, "null / empty / oversized argument");
 	BLA_REQUIRE(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, BLA_ERR_INVALID, "rank %d / world %d (max %d)", rank, world, kMaxWorld);
 	bla_dp* dp = new bla_dp();
-	dp->rank = rank; dp->world = world; dp->count = count;
+	dp->id = g_next_dp_id.fetch_add(1);
+	dp->rank = rank; dp->world = world; dp->count = count; dp->device = ctx().device;
 	dp->padded = (count + 1023) / 1024 * 1024;
 	const unsigned n4 = (unsigned)((count + 3) / 4);
 	dp->per4 = (n4 + world - 1) / world;
 	dp->red_off = 2 * dp->padded * sizeof(float);
-	dp->flags_off = dp->red_off + 2 * (size_t)dp->per4 * 16;
-	dp->bytes = dp->flags_off + 4096;
+	dp->bytes = dp->red_off + 2 * (size_t)dp->per4 * 16;
 	// two shots pay a second flag round to move 2/R of a bucket per link instead of a whole one: worth it from four ranks up
 	const char* algo = getenv("BLA_DP_ALGO");
 	dp->twoshot = algo ? strcmp(algo, "twoshot") == 0 : world >= 4;
-	void* p = nullptr;
+	void *p = nullptr, *f = nullptr, *s = nullptr;
 	hipError_t e = hipExtMallocWithFlags(&p, dp->bytes, hipDeviceMallocFinegrained);
 	if (e != hipSuccess) { delete dp; return hip_fail(e, "hipExtMallocWithFlags(fine-grained exchange buffer)"); }
-	dp->base = (char*)p;
-	e = hipMemset(p, 0, dp->bytes);
-	void* s = nullptr;
+	dp->flags_uncached = hipExtMallocWithFlags(&f, 4096, hipDeviceMallocUncached) == hipSuccess;
+	if (!dp->flags_uncached) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained); }
+	if (e == hipSuccess) e = hipMemset(p, 0, dp->bytes);
+	if (e == hipSuccess) e = hipMemset(f, 0, 4096);
 	if (e == hipSuccess) e = hipMalloc(&s, 64);
 	if (e == hipSuccess) e = hipMemset(s, 0, 64);
 	if (e == hipSuccess) e = hipDeviceSynchronize();
-	if (e != hipSuccess) { (void)hipFree(p); if (s) (void)hipFree(s); delete dp; return hip_fail(e, "exchange state allocation"); }
-	dp->state = (unsigned*)s;
-	for (int r = 0; r < kMaxWorld; r++) dp->peer[r] = nullptr;
-	dp->peer[rank] = dp->base;
+	if (e != hipSuccess) { (void)hipFree(p); if (f) (void)hipFree(f); if (s) (void)hipFree(s); delete dp; return hip_fail(e, "exchange state allocation"); }
+	dp->base = (char*)p; dp->flags = (char*)f; dp->state = (unsigned*)s;
+	for (int r = 0; r < kMaxWorld; r++) { dp->peer[r] = nullptr; dp->peer_flags[r] = nullptr; dp->peer_ipc[r] = false; }
+	dp->peer[rank] = dp->base; dp->peer_flags[rank] = dp->flags;
 	dp->connected = world == 1;
 	*out = dp;
 	return BLA_OK;
@@ -263,43 +298,69 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 
 bla_status bla_dp_destroy(bla_dp* dp) {
 	if (!dp) return BLA_OK;
+	(void)hipSetDevice(dp->device);
 	(void)hipDeviceSynchronize();
 	for (int r = 0; r < dp->world; r++)
-		if (r != dp->rank && dp->peer[r]) (void)hipIpcCloseMemHandle(dp->peer[r]);
+		if (r != dp->rank && dp->peer_ipc[r]) {
+			if (dp->peer[r]) (void)hipIpcCloseMemHandle(dp->peer[r]);
+			if (dp->peer_flags[r]) (void)hipIpcCloseMemHandle(dp->peer_flags[r]);
+		}
 	(void)hipFree(dp->base);
+	(void)hipFree(dp->flags);
 	(void)hipFree(dp->state);
 	delete dp;
+	if (ctx().ready) (void)hipSetDevice(ctx().device);
 	return BLA_OK;
 }
 
-/* 64 opaque bytes that another process passes to bla_dp_connect (hipIpcMemHandle_t of the exchange buffer). */
-bla_status bla_dp_export(bla_dp* dp, void* handle64) {
-	BLA_REQUIRE(dp && handle64, BLA_ERR_INVALID, "null argument");
-	static_assert(sizeof(hipIpcMemHandle_t) == BLA_DP_HANDLE_BYTES, "handle size");
-	hipIpcMemHandle_t h;
-	BLA_HIP(hipIpcGetMemHandle(&h, dp->base));
-	memcpy(handle64, &h, sizeof h);
+/* BLA_DP_HANDLE_BYTES opaque bytes that the other ranks pass to bla_dp_connect. */
+bla_status bla_dp_export(bla_dp* dp, void* handle) {
+	BLA_REQUIRE(dp && handle, BLA_ERR_INVALID, "null argument");
+	DpHandle h;
+	memset(&h, 0, sizeof h);
+	BLA_HIP(hipIpcGetMemHandle(&h.data, dp->base));
+	BLA_HIP(hipIpcGetMemHandle(&h.flags, dp->flags));
+	h.pid = (unsigned long long)getpid(); h.nonce = process_nonce();
+	h.base = (unsigned long long)(uintptr_t)dp->base; h.flags_base = (unsigned long long)(uintptr_t)dp->flags;
+	h.device = dp->device; h.magic = 0xB1A0D902u;
+	memset(handle, 0, BLA_DP_HANDLE_BYTES);
+	memcpy(handle, &h, sizeof h);
 	return BLA_OK;
 }
 
-/* handles: world x 64 bytes, slot r = what rank r exported (the own slot is ignored).  Every rank must have created its
- * exchange object before any rank connects (the caller's handle exchange is that barrier). */
+/* handles: world x BLA_DP_HANDLE_BYTES, slot r = what rank r exported (the own slot is ignored).  Every rank must have created its
+ * exchange object before any rank connects (the caller's handle exchange is that barrier).  Ranks of another process are mapped
+ * through IPC; ranks of this process are addressed directly (peer access is enabled when they sit on another device). */
 bla_status bla_dp_connect(bla_dp* dp, const void* handles) {
 	BLA_REQUIRE(dp && handles, BLA_ERR_INVALID, "null argument");
 	BLA_REQUIRE(!dp->connected || dp->world == 1, BLA_ERR_INVALID, "already connected");
+	BLA_HIP(hipSetDevice(dp->device));
 	for (int r = 0; r < dp->world; r++) {
 		if (r == dp->rank) continue;
-		hipIpcMemHandle_t h;
+		DpHandle h;
 		memcpy(&h, (const char*)handles + (size_t)r * BLA_DP_HANDLE_BYTES, sizeof h);
-		void* p = nullptr;
-		hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+		BLA_REQUIRE(h.magic == 0xB1A0D902u, BLA_ERR_INVALID, "slot %d does not hold a bla_dp_export blob", r);
+		if (h.pid == (unsigned long long)getpid() && h.nonce == process_nonce()) {
+			if (h.device != dp->device) {
+				hipError_t e = hipDeviceEnablePeerAccess(h.device, 0);
+				if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+				else if (e != hipSuccess) { set_error("hipDeviceEnablePeerAccess(device %d -> %d): %s", dp->device, h.device, hipGetErrorString(e)); return BLA_ERR_HIP; }
+			}
+			dp->peer[r] = (void*)(uintptr_t)h.base; dp->peer_flags[r] = (void*)(uintptr_t)h.flags_base;
+			continue;
+		}
+		void *p = nullptr, *f = nullptr;
+		hipError_t e = hipIpcOpenMemHandle(&p, h.data, hipIpcMemLazyEnablePeerAccess);
+		if (e == hipSuccess) e = hipIpcOpenMemHandle(&f, h.flags, hipIpcMemLazyEnablePeerAccess);
 		if (e != hipSuccess) {
+			if (p) (void)hipIpcCloseMemHandle(p);
 			set_error("hipIpcOpenMemHandle(rank %d's exchange buffer): %s", r, hipGetErrorString(e));
 			return BLA_ERR_HIP;
 		}
-		dp->peer[r] = p;
+		dp->peer[r] = p; dp->peer_flags[r] = f; dp->peer_ipc[r] = true;
 	}
 	dp->connected = true;
+	if (ctx().ready) (void)hipSetDevice(ctx().device);
 	return BLA_OK;
 }
 
@@ -318,25 +379,30 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 	DpKernelArgs a = {};
 	for (int r = 0; r < dp->world; r++) {
 		a.src[r] = (const float*)((char*)dp->peer[r] + (size_t)(parity & 1) * dp->padded * sizeof(float));
-		a.peer_flags[r] = (unsigned*)((char*)dp->peer[r] + dp->flags_off);
+		a.peer_flags[r] = (unsigned*)dp->peer_flags[r];
 	}
-	a.flags = (unsigned*)(dp->base + dp->flags_off);
+	a.flags = (unsigned*)dp->flags;
 	a.state = dp->state;
 	a.out = d_out; a.target = d_target; a.alpha = alpha;
 	a.n4 = (unsigned)((dp->count + 3) / 4); a.count = (unsigned)dp->count;
 	a.world = dp->world; a.rank = dp->rank;
-	const unsigned cus = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+	unsigned cus = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+	// Every workgroup of an exchange launch spins until the peers' launches have shown up, so all launches of a group must be resident
+	// at once.  One rank per GPU: always true.  Several ranks REHEARSING on one GPU (tests, BLA_BENCH_SHARE_GPU) share its workgroup
+	// slots with each other and with the gradient kernels the spinning ranks wait for: BLA_DP_MAX_BLOCKS caps the grid there.
+	static const unsigned max_blocks = [] { const char* e = getenv("BLA_DP_MAX_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
+	if (max_blocks && cus > max_blocks) cus = max_blocks;
 	if (dp->twoshot && dp->world > 1) {
 		for (int r = 0; r < dp->world; r++) {
 			a.red[r] = (const float*)((char*)dp->peer[r] + dp->red_off + (size_t)(parity & 1) * dp->per4 * 16);
-			a.peer_flags_b[r] = (unsigned*)((char*)dp->peer[r] + dp->flags_off + 2048);
+			a.peer_flags_b[r] = (unsigned*)((char*)dp->peer_flags[r] + 2048);
 		}
 		a.red_self = (float*)(dp->base + dp->red_off + (size_t)(parity & 1) * dp->per4 * 16);
-		a.flags_b = (unsigned*)(dp->base + dp->flags_off + 2048);
+		a.flags_b = (unsigned*)(dp->flags + 2048);
 		a.per4 = dp->per4;
 		// the second phase waits for workgroups of this same launch (here and on the peers): keep the grid fully resident
 		unsigned blocks = (a.n4 - a.per4 + 255) / 256;
-		const unsigned cap = cus / 2 < 128 ? (cus / 2 ? cus / 2 : 1) : 128;
+		const unsigned cap = max_blocks ? cus : (cus / 2 < 128 ? (cus / 2 ? cus / 2 : 1) : 128);
 		if (blocks > cap) blocks = cap;
 		if (blocks < 1) blocks = 1;
 		hipLaunchKernelGGL(dp_allreduce_twoshot_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);

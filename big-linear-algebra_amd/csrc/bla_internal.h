@@ -19,6 +19,7 @@ struct Context {
 	char arch[64] = {0};
 };
 
+// The calling thread's current context: the one bla_context_set_current installed, else the process default (bla_init).
 Context& ctx();
 void set_error(const char* fmt, ...);
 bla_status hip_fail(hipError_t e, const char* what);
@@ -51,6 +52,9 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 // group_norm_ddx with the ReLU gate on its input and the residual gradient added to its output (either may be NULL), model/cifar_unet.c:1204-1205,1219
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
                                 int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend);
+
+// bla_dp.hip: identity of an exchange object that survives address reuse (a destroyed and re-created object never has the same id)
+unsigned long long dp_identity(const bla_dp* dp);
 
 #define BLA_HIP(call)                                               \
 	do {                                                            \

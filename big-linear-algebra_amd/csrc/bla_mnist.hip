@@ -35,7 +35,7 @@ struct bla_mnist_nn {
 	std::vector<void*> owned;
 	hipGraph_t graph; hipGraphExec_t graph_exec; bool graph_ready; int graph_colsum; float graph_lr;
 	// data-parallel step: one graph per gradient-bucket parity (the exchange object double-buffers the bucket)
-	hipGraph_t dp_graph[2]; hipGraphExec_t dp_exec[2]; bool dp_ready[2]; bla_dp* dp_bound; float dp_lr; unsigned long long dp_steps;
+	hipGraph_t dp_graph[2]; hipGraphExec_t dp_exec[2]; bool dp_ready[2]; unsigned long long dp_bound_id; float dp_lr; unsigned long long dp_steps;
 };
 
 using namespace bla;
@@ -68,7 +68,7 @@ bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) 
 	nn->count = o;
 	nn->own_buckets = true;
 	nn->graph_ready = false;
-	nn->dp_ready[0] = nn->dp_ready[1] = false; nn->dp_bound = nullptr; nn->dp_lr = 0.f; nn->dp_steps = 0;
+	nn->dp_ready[0] = nn->dp_ready[1] = false; nn->dp_bound_id = 0; nn->dp_lr = 0.f; nn->dp_steps = 0;
 	const size_t B = batch;
 	st = dev_alloc(nn, &nn->params, o); if (st) return st;
 	st = dev_alloc(nn, &nn->grads, o); if (st) return st;
@@ -84,8 +84,10 @@ bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) 
 	st = dev_alloc(nn, &nn->dz3, sizes[3] * B); if (st) return st;
 	st = dev_alloc(nn, &nn->dz2, sizes[2] * B); if (st) return st;
 	st = dev_alloc(nn, &nn->dz1, sizes[1] * B); if (st) return st;
-	BLA_HIP(hipMemset(nn->params, 0, o * sizeof(float)));
-	BLA_HIP(hipMemset(nn->grads, 0, o * sizeof(float)));
+	// on the context's stream and waited for: that stream is non-blocking, a NULL-stream memset would not order against the first step
+	BLA_HIP(hipMemsetAsync(nn->params, 0, o * sizeof(float), ctx().stream));
+	BLA_HIP(hipMemsetAsync(nn->grads, 0, o * sizeof(float), ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	void* ws;   // split-K slabs: grow the shared workspace now so that no step (or graph capture) ever reallocates
 	st = ensure_workspace((size_t)64 << 20, &ws); if (st) return st;
 	*out = nn;
@@ -111,6 +113,9 @@ float* bla_mnist_nn_labels(bla_mnist_nn* nn) { return nn ? nn->y : nullptr; }
 bla_status bla_mnist_nn_use_buckets(bla_mnist_nn* nn, float* d_params, float* d_grads) {
 	BLA_REQUIRE(nn && d_params && d_grads, BLA_ERR_INVALID, "null argument");
 	BLA_REQUIRE(!nn->graph_ready, BLA_ERR_INVALID, "buckets cannot change after a graph was captured");
+	for (int i = 0; i < 2; i++)   // recorded data-parallel steps hold the old parameter bucket: drop them, the next dp_step records again
+		if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
+	BLA_HIP(hipDeviceSynchronize());
 	BLA_HIP(hipMemcpy(d_params, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToDevice));
 	nn->params = d_params; nn->grads = d_grads; nn->own_buckets = false;
 	return BLA_OK;
@@ -334,10 +339,12 @@ bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, floa
 	BLA_REQUIRE(colsum_mode == BLA_COLSUM_INTENDED, BLA_ERR_INVALID, "a sharded batch needs BLA_COLSUM_INTENDED (true row sums)");
 	BLA_REQUIRE(bla_dp_count(dp) == nn->count, BLA_ERR_SHAPE, "exchange bucket holds %zu floats, the trainer has %zu parameters", bla_dp_count(dp), nn->count);
 	hipStream_t s = pick_stream(stream);
-	if (nn->dp_bound != dp || nn->dp_lr != lr) {
+	// (the exchange object's id, not its address: a destroyed and re-created object may come back at the same address, and the recorded
+	// graphs would then hold the freed buckets and closed peer mappings)
+	if (nn->dp_bound_id != dp_identity(dp) || nn->dp_lr != lr) {
 		for (int i = 0; i < 2; i++)
 			if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
-		nn->dp_bound = dp; nn->dp_lr = lr;
+		nn->dp_bound_id = dp_identity(dp); nn->dp_lr = lr;
 	}
 	const int par = (int)(nn->dp_steps & 1);
 	if (!nn->dp_ready[par]) {

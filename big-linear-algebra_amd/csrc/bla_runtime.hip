@@ -8,11 +8,12 @@
 
 namespace bla {
 
-static Context g_ctx;
+static Context g_ctx;                          // the process default (bla_init)
+static thread_local Context* t_ctx = nullptr;  // bla_context_set_current
 static thread_local char g_err[512] = "no error";
 static std::mutex g_mu;
 
-Context& ctx() { return g_ctx; }
+Context& ctx() { return t_ctx ? *t_ctx : g_ctx; }
 
 void set_error(const char* fmt, ...) {
 	va_list ap;
@@ -27,7 +28,7 @@ bla_status hip_fail(hipError_t e, const char* what) {
 }
 
 bla_status require_ready() {
-	if (!g_ctx.ready) {
+	if (!ctx().ready) {
 		set_error("bla runtime not initialised: call bla_init(device) first (no CPU fallback exists)");
 		return BLA_ERR_NO_DEVICE;
 	}
@@ -35,19 +36,20 @@ bla_status require_ready() {
 }
 
 bla_status ensure_workspace(size_t bytes, void** out) {
-	if (bytes > g_ctx.workspace_bytes) {
+	Context& c = ctx();
+	if (bytes > c.workspace_bytes) {
 		// Grow-only.  Callers serialise on one stream, so freeing after a sync is safe.
-		if (g_ctx.workspace) {
+		if (c.workspace) {
 			BLA_HIP(hipDeviceSynchronize());
-			BLA_HIP(hipFree(g_ctx.workspace));
-			g_ctx.workspace = nullptr;
-			g_ctx.workspace_bytes = 0;
+			BLA_HIP(hipFree(c.workspace));
+			c.workspace = nullptr;
+			c.workspace_bytes = 0;
 		}
 		size_t want = bytes < (size_t)(64u << 20) ? (size_t)(64u << 20) : bytes;
-		BLA_HIP(hipMalloc(&g_ctx.workspace, want));
-		g_ctx.workspace_bytes = want;
+		BLA_HIP(hipMalloc(&c.workspace, want));
+		c.workspace_bytes = want;
 	}
-	*out = g_ctx.workspace;
+	*out = c.workspace;
 	return BLA_OK;
 }
 
@@ -102,9 +104,8 @@ int bla_device_count(void) {
 	return n;
 }
 
-bla_status bla_init(int device) {
-	std::lock_guard<std::mutex> lk(g_mu);
-	if (g_ctx.ready && g_ctx.device == device) return BLA_OK;
+// create stream / counters of one context on `device` (the caller holds g_mu)
+static bla_status open_context(Context& c, int device) {
 	int n = bla_device_count();
 	if (n <= 0) {
 		set_error("no HIP device visible (hipGetDeviceCount = %d); this library has no CPU path", n);
@@ -118,35 +119,82 @@ bla_status bla_init(int device) {
 		set_error("device %d is %s; libbla_hip.so carries gfx950 code objects only", device, prop.gcnArchName);
 		return BLA_ERR_NO_DEVICE;
 	}
-	if (g_ctx.ready) {  // switching device: drop the old stream/workspace
-		(void)hipStreamDestroy(g_ctx.stream);
-		if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
-		if (g_ctx.tile_counters) (void)hipFree(g_ctx.tile_counters);
-		g_ctx = Context();
-	}
-	BLA_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-	BLA_HIP(hipMalloc((void**)&g_ctx.tile_counters, (16384 + 64) * sizeof(unsigned)));   // + 64 words that stay zero (zero_word())
-	BLA_HIP(hipMemset(g_ctx.tile_counters, 0, (16384 + 64) * sizeof(unsigned)));
-	g_ctx.device = device;
-	g_ctx.num_cus = prop.multiProcessorCount;
-	strncpy(g_ctx.arch, prop.gcnArchName, sizeof(g_ctx.arch) - 1);
-	g_ctx.ready = true;
+	BLA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+	BLA_HIP(hipMalloc((void**)&c.tile_counters, (16384 + 64) * sizeof(unsigned)));   // + 64 words that stay zero (zero_word())
+	// zeroed on the context's own stream and waited for: the stream is non-blocking, a NULL-stream memset would not order against it
+	BLA_HIP(hipMemsetAsync(c.tile_counters, 0, (16384 + 64) * sizeof(unsigned), c.stream));
+	BLA_HIP(hipStreamSynchronize(c.stream));
+	c.device = device;
+	c.num_cus = prop.multiProcessorCount;
+	strncpy(c.arch, prop.gcnArchName, sizeof(c.arch) - 1);
+	c.ready = true;
 	return BLA_OK;
+}
+
+static void close_context(Context& c) {
+	if (!c.ready) return;
+	(void)hipSetDevice(c.device);
+	(void)hipDeviceSynchronize();
+	(void)hipStreamDestroy(c.stream);
+	if (c.workspace) (void)hipFree(c.workspace);
+	if (c.tile_counters) (void)hipFree(c.tile_counters);
+	c = Context();
+}
+
+bla_status bla_init(int device) {
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (g_ctx.ready && g_ctx.device == device) {
+		if (!t_ctx) BLA_HIP(hipSetDevice(device));
+		return BLA_OK;
+	}
+	close_context(g_ctx);   // switching device: drop the old stream / workspace
+	bla_status st = open_context(g_ctx, device);
+	if (st) close_context(g_ctx);
+	return st;
 }
 
 bla_status bla_shutdown(void) {
 	std::lock_guard<std::mutex> lk(g_mu);
-	if (!g_ctx.ready) return BLA_OK;
-	(void)hipSetDevice(g_ctx.device);
-	(void)hipDeviceSynchronize();
-	(void)hipStreamDestroy(g_ctx.stream);
-	if (g_ctx.workspace) (void)hipFree(g_ctx.workspace);
-	if (g_ctx.tile_counters) (void)hipFree(g_ctx.tile_counters);
-	g_ctx = Context();
+	close_context(g_ctx);
 	return BLA_OK;
 }
 
-int bla_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
+struct bla_context { Context c; };
+
+/* Further contexts beside the default one: a context = {device, stream, split-K workspace, arrival counters}.  A host that drives
+ * several GPUs (or several replicas on one GPU) from ONE process creates one context per rank and makes it current on the calling
+ * thread before it issues that rank's bla_* calls. */
+bla_status bla_context_create(bla_context** out, int device) {
+	BLA_REQUIRE(out, BLA_ERR_INVALID, "null out pointer");
+	std::lock_guard<std::mutex> lk(g_mu);
+	bla_context* c = new bla_context();
+	bla_status st = open_context(c->c, device);
+	if (st) { close_context(c->c); delete c; }
+	else *out = c;
+	Context& cur = ctx();   // open_context moved this thread to `device`: go back to where the caller was
+	if (cur.ready) (void)hipSetDevice(cur.device);
+	return st;
+}
+
+bla_status bla_context_set_current(bla_context* c) {
+	t_ctx = c ? &c->c : nullptr;
+	Context& cur = ctx();
+	if (cur.ready) BLA_HIP(hipSetDevice(cur.device));
+	return BLA_OK;
+}
+
+bla_status bla_context_destroy(bla_context* c) {
+	if (!c) return BLA_OK;
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (t_ctx == &c->c) t_ctx = nullptr;
+	close_context(c->c);
+	delete c;
+	Context& cur = ctx();
+	if (cur.ready) (void)hipSetDevice(cur.device);
+	return BLA_OK;
+}
+
+int bla_is_initialized(void) { return ctx().ready ? 1 : 0; }
 const char* bla_last_error(void) { return g_err; }
 const char* bla_version(void) { return "bla-hip 0.1 (gfx950)"; }
 
@@ -166,7 +214,7 @@ bla_status bla_device_name(char* buf, int buflen) {
 	bla_status s = require_ready();
 	if (s) return s;
 	BLA_REQUIRE(buf && buflen > 0, BLA_ERR_INVALID, "null buffer");
-	snprintf(buf, buflen, "%s (%d CUs)", g_ctx.arch, g_ctx.num_cus);
+	snprintf(buf, buflen, "%s (%d CUs)", ctx().arch, ctx().num_cus);
 	return BLA_OK;
 }
 
@@ -231,7 +279,7 @@ bla_status bla_stream_sync(void* stream) {
 	return BLA_OK;
 }
 
-void* bla_default_stream(void) { return (void*)g_ctx.stream; }
+void* bla_default_stream(void) { return (void*)ctx().stream; }
 
 bla_status bla_event_create(void** ev) {
 	bla_status s = require_ready();

@@ -14,6 +14,7 @@ from . import native
 LAYER_SIZES = (784, 256, 128, 10)                 # model/mnist_nn.c:25-28
 LEARN_RATE = float(np.float32(-0.02))             # float epoch_learn_rate = -SGD_LEARN_RATE_MULTIPLIER, :186
 COLSUM_AS_WRITTEN, COLSUM_INTENDED = 0, 1
+HANDLE_BYTES = 256                                # BLA_DP_HANDLE_BYTES
 ACTIVATION_NAMES = ["z1", "a1", "z2", "a2", "z3", "a3", "dz3", "dz2", "dz1"]
 
 
@@ -121,10 +122,63 @@ class MnistNN:
         f = self.L.bla_mnist_nn_dp_step if graph else self.L.bla_mnist_nn_dp_step_direct
         native.check(f(self.h, exchange.h, stream, lr, self.colsum_mode))
 
+    def dp_step_rccl(self, comm, lr=LEARN_RATE, stream=None):
+        """One data-parallel step over the library collective: forward + backward, ncclAllReduce(SUM) of the gradient bucket, update."""
+        native.check(self.L.bla_mnist_nn_dp_step_rccl(self.h, comm.h, stream, lr, self.colsum_mode))
+
+
+class Context:
+    """bla_context_*: one more {device, stream, workspace} beside the default one, for hosts that drive several ranks from one
+    process.  make_current() installs it on the calling thread; every bla_* call issued after that belongs to this rank."""
+
+    def __init__(self, device=0):
+        self.L = native.lib()
+        h = C.c_void_p()
+        native.check(self.L.bla_context_create(C.byref(h), device))
+        self.h = h
+
+    def make_current(self):
+        native.check(self.L.bla_context_set_current(self.h))
+        return self
+
+    @staticmethod
+    def restore_default():
+        native.check(native.lib().bla_context_set_current(None))
+
+    def close(self):
+        if self.h:
+            self.L.bla_context_destroy(self.h)
+            self.h = None
+
+
+class RcclComm:
+    """bla_dp_rccl_*: the library collective (ncclAllReduce SUM over xGMI) behind the C-ABI.  `broadcast_bytes(b) -> bytes` hands rank 0's
+    128-byte unique id to every rank over any host channel."""
+
+    def __init__(self, rank, world, broadcast_bytes=None):
+        self.L = native.lib()
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            native.check(self.L.bla_dp_rccl_unique_id(ident))
+        raw = ident.raw
+        if world > 1:
+            raw = broadcast_bytes(raw if rank == 0 else None)
+        h = C.c_void_p()
+        native.check(self.L.bla_dp_rccl_init(C.byref(h), raw, rank, world))
+        self.h, self.rank, self.world = h, rank, world
+
+    def allreduce(self, ptr, count, stream=None):
+        native.check(self.L.bla_dp_rccl_allreduce_f32(self.h, stream, ptr, count))
+
+    def close(self):
+        if self.h:
+            self.L.bla_dp_rccl_destroy(self.h)
+            self.h = None
+
 
 class Exchange:
     """bla_dp_*: the gradient exchange of the data-parallel step.  `all_gather_bytes(b) -> [bytes per rank]` is any
-    host-side channel (torch.distributed.all_gather_object, MPI, ...): it only carries the 64-byte IPC handles once."""
+    host-side channel (torch.distributed.all_gather_object, MPI, ...): it only carries the 256-byte handle blobs once."""
 
     def __init__(self, rank, world, count, all_gather_bytes=None):
         """With `all_gather_bytes` the peers are connected here; without it (and world > 1) call export() / connect() yourself,
@@ -137,12 +191,12 @@ class Exchange:
             self.connect(all_gather_bytes(self.export()))
 
     def export(self):
-        buf = C.create_string_buffer(64)
+        buf = C.create_string_buffer(HANDLE_BYTES)
         native.check(self.L.bla_dp_export(self.h, buf))
         return buf.raw
 
     def connect(self, handles):
-        assert len(handles) == self.world and all(len(x) == 64 for x in handles)
+        assert len(handles) == self.world and all(len(x) == HANDLE_BYTES for x in handles)
         native.check(self.L.bla_dp_connect(self.h, b"".join(handles)))
 
     def bucket(self, parity):

@@ -52,6 +52,7 @@ SIGNATURES = {
     "bla_init": (_I, [_I]), "bla_shutdown": (_I, []), "bla_is_initialized": (_I, []), "bla_device_count": (_I, []),
     "bla_last_error": (C.c_char_p, []), "bla_status_string": (C.c_char_p, [_I]), "bla_version": (C.c_char_p, []),
     "bla_device_name": (_I, [C.c_char_p, _I]),
+    "bla_context_create": (_I, [C.POINTER(_VP), _I]), "bla_context_set_current": (_I, [_VP]), "bla_context_destroy": (_I, [_VP]),
     "bla_malloc": (_I, [C.POINTER(_VP), _SZ]), "bla_free": (_I, [_VP]),
     "bla_memcpy_h2d": (_I, [_VP, _VP, _SZ, _VP]), "bla_memcpy_d2h": (_I, [_VP, _VP, _SZ, _VP]),
     "bla_memcpy_d2d": (_I, [_VP, _VP, _SZ, _VP]), "bla_memset": (_I, [_VP, _I, _SZ, _VP]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "bla_dp_export": (_I, [_VP, _VP]), "bla_dp_connect": (_I, [_VP, _VP]),
     "bla_dp_bucket": (_VP, [_VP, _I]), "bla_dp_count": (C.c_size_t, [_VP]),
     "bla_dp_allreduce_f32": (_I, [_VP, _VP, _I, _VP, _VP, _F]), "bla_dp_status": (_I, [_VP, C.POINTER(_I)]),
+    "bla_dp_rccl_unique_id": (_I, [_VP]), "bla_dp_rccl_init": (_I, [C.POINTER(_VP), _VP, _I, _I]), "bla_dp_rccl_destroy": (_I, [_VP]),
+    "bla_dp_rccl_allreduce_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_mnist_nn_dp_step_rccl": (_I, [_VP, _VP, _VP, _F, _I]),
     "bla_mnist_nn_dp_step": (_I, [_VP, _VP, _VP, _F, _I]), "bla_mnist_nn_dp_step_direct": (_I, [_VP, _VP, _VP, _F, _I]),
 }
 

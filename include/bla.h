@@ -55,6 +55,16 @@ BLA_API const char* bla_status_string(bla_status s);
 BLA_API const char* bla_version(void);
 BLA_API bla_status bla_device_name(char* buf, int buflen);   /* gcnArchName of the active device */
 
+/* Further contexts beside the default one bla_init creates: a context = {device, stream, split-K workspace, arrival counters}.
+ * A host that drives several GPUs -- or several replicas on one GPU -- from ONE process ("single-process multi-device,
+ * one host thread or one stream per device") creates one context per rank and makes it current on the calling thread before it issues
+ * that rank's bla_* calls; NULL = back to the default context.  Objects (trainers, exchange objects, device memory) belong to the
+ * device of the context that was current when they were created. */
+typedef struct bla_context bla_context;
+BLA_API bla_status bla_context_create(bla_context** out, int device);
+BLA_API bla_status bla_context_set_current(bla_context* c);
+BLA_API bla_status bla_context_destroy(bla_context* c);
+
 BLA_API bla_status bla_malloc(void** d_ptr, size_t bytes);
 BLA_API bla_status bla_free(void* d_ptr);
 BLA_API bla_status bla_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
@@ -306,12 +316,14 @@ BLA_API bla_status bla_mnist_nn_graph_step(bla_mnist_nn* nn, void* stream, float
  * (used alternately) in fine-grained memory that the peers map through IPC and read directly over xGMI; the sum is
  * taken in rank order on every rank (bit-identical results) and the update is fused.  See csrc/bla_dp.hip. */
 typedef struct bla_dp bla_dp;
-#define BLA_DP_HANDLE_BYTES 64
+#define BLA_DP_HANDLE_BYTES 256
 BLA_API bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count /* floats per bucket */);
 BLA_API bla_status bla_dp_destroy(bla_dp* dp);
-/* 64 opaque bytes for the other ranks (exchange them with any host-side channel: MPI, torch.distributed, a file) */
-BLA_API bla_status bla_dp_export(bla_dp* dp, void* handle64);
-/* handles: world x 64 bytes, slot r = rank r's export (own slot ignored); call once, after every rank has exported */
+/* BLA_DP_HANDLE_BYTES opaque bytes for the other ranks (exchange them with any host-side channel: MPI, torch.distributed, a file,
+ * or a plain array when all ranks live in one process) */
+BLA_API bla_status bla_dp_export(bla_dp* dp, void* handle);
+/* handles: world x BLA_DP_HANDLE_BYTES, slot r = rank r's export (own slot ignored); call once, after every rank has exported.
+ * Ranks in other processes are mapped through IPC, ranks of the calling process (other contexts) are addressed directly. */
 BLA_API bla_status bla_dp_connect(bla_dp* dp, const void* handles);
 BLA_API float* bla_dp_bucket(bla_dp* dp, int parity);   /* device pointer of this rank's bucket 0 / 1 */
 BLA_API size_t bla_dp_count(const bla_dp* dp);
@@ -324,6 +336,18 @@ BLA_API bla_status bla_dp_status(bla_dp* dp, int* status);
 BLA_API bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
 /* the same step issued directly on the stream (seven launches from one host call); may be mixed with the graph form */
 BLA_API bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
+
+/* ---- the same exchange through the library collective: RCCL ncclAllReduce(ncclFloat, ncclSum) over xGMI (north_star) ----
+ * Rank 0 makes the 128-byte unique id, the host program hands it to the other ranks over any channel, every rank creates its
+ * communicator on its current context's device (one process per GPU, or one context per GPU in one process). */
+typedef struct bla_rccl bla_rccl;
+#define BLA_RCCL_ID_BYTES 128
+BLA_API bla_status bla_dp_rccl_unique_id(void* id128);
+BLA_API bla_status bla_dp_rccl_init(bla_rccl** out, const void* id128, int rank, int world);   /* ncclCommInitRank; collective */
+BLA_API bla_status bla_dp_rccl_destroy(bla_rccl* c);
+BLA_API bla_status bla_dp_rccl_allreduce_f32(bla_rccl* c, void* stream, float* d_buf, size_t count);   /* in place, SUM, async on stream */
+/* forward + backward into the trainer's gradient bucket, ncclAllReduce of the bucket, params += lr * sum (model/mnist_nn.c:218-315 sharded) */
+BLA_API bla_status bla_mnist_nn_dp_step_rccl(bla_mnist_nn* nn, bla_rccl* c, void* stream, float lr, int colsum_mode);
 
 #ifdef __cplusplus
 }

@@ -22,28 +22,40 @@ def dev():
     return bla
 
 
-def run_ranks(world, tmp, steps, per, algo):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLA_DP_ALGO=algo)
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(tmp), str(steps), str(per)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+def run_ranks(world, tmp, steps, per, algo, ranks_per_process=1):
+    """`world` ranks as world / ranks_per_process processes on the one GPU (the box allows 6 processes on the card: 8 ranks need
+    several ranks per process, each in its own bla context with its own stream -- GPU_MAX_HW_QUEUES gives every stream its own
+    hardware queue so that the launches of one process's ranks run side by side, as they would on separate GPUs)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLA_DP_ALGO=algo, GPU_MAX_HW_QUEUES="8")
+    if world > 4:
+        env["BLA_DP_MAX_BLOCKS"] = "48"        # all ranks' spinning exchange launches and the gradient kernels they wait for share one GPU here
+    procs = [subprocess.Popen([sys.executable, WORKER, str(lo), str(min(lo + ranks_per_process, world)), str(world), str(tmp), str(steps), str(per)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for lo in range(0, world, ranks_per_process)]
     outs, failed = [], False
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=240)
+            o, _ = p.communicate(timeout=300)
         except subprocess.TimeoutExpired:
             p.kill(); o, _ = p.communicate(); failed = True
         outs.append(o)
         failed |= p.returncode != 0
     assert not failed, "\n---\n".join(outs)
+    print("\n".join(o.strip().splitlines()[-1] for o in outs if o.strip()))
     return [np.load(os.path.join(tmp, f"result{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,algo", [(2, "oneshot"), (2, "twoshot"), (4, "oneshot"), (4, "twoshot"), (3, "twoshot")])
-def test_exchange_between_processes(dev, world, algo, tmp_path):
+# (world, algorithm, ranks per process, per-rank batch).  The last three are BASELINE configs[3]: 8 ranks x 256 = global batch 2048,
+# in one process (8 contexts), in 4 processes x 2 ranks (IPC and direct peers mixed), in both forms of the exchange.
+CASES = [(2, "oneshot", 1, 64), (2, "twoshot", 1, 64), (4, "oneshot", 1, 64), (4, "twoshot", 1, 64), (3, "twoshot", 1, 64), (5, "twoshot", 1, 64),
+         (2, "oneshot", 2, 64), (8, "twoshot", 8, 256), (8, "oneshot", 8, 256), (8, "twoshot", 2, 256)]
+
+
+@pytest.mark.parametrize("world,algo,rpp,per", CASES)
+def test_exchange_between_ranks(dev, world, algo, rpp, per, tmp_path):
     """algo: one kernel pulling whole peer buckets, or reduce-scatter + all-gather inside one kernel (the default from 4 ranks up);
     both sum in rank order, so the expected bits are the same."""
-    steps, per = 3, 64
-    res = run_ranks(world, str(tmp_path), steps, per, algo)
+    steps = 3
+    res = run_ranks(world, str(tmp_path), steps, per, algo, rpp)
     count = 10007
     tgt = np.full(count, 1.0, np.float32)
     for rnd in range(3):
@@ -58,7 +70,7 @@ def test_exchange_between_processes(dev, world, algo, tmp_path):
         np.testing.assert_allclose(res[r]["target"], tgt, rtol=1e-6, atol=1e-6)   # the update may contract into an FMA
         assert np.array_equal(res[r]["params"], res[0]["params"]), f"rank {r} parameters differ from rank 0's"
 
-    # single device, full batch, same trainer
+    # single device, full batch (= per x world columns: 2048 for configs[3]), same trainer
     mn = dev.mnist_nn
     gB = per * world
     nn = mn.MnistNN(gB, colsum_mode=mn.COLSUM_INTENDED)
@@ -77,6 +89,52 @@ def test_exchange_between_processes(dev, world, algo, tmp_path):
     assert err <= 1e-6, err
     # the update itself (what the exchange carries) to 1e-4 of its own size
     assert np.linalg.norm((got - p0) - (single - p0)) <= 1e-4 * np.linalg.norm(single - p0)
+
+
+def test_exchange_object_identity_survives_address_reuse(dev):
+    """recorded data-parallel graphs are bound to the exchange object's id, not its address -- destroying the object and
+    creating a new one (very likely at the same address) must re-record, not replay graphs that hold the freed buckets."""
+    mn = dev.mnist_nn
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    x_raw = randint(7, (784, 64), 256).astype(np.float32)
+    lab = randint(8, (64,), 10); y = np.zeros((10, 64), np.float32); y[lab, np.arange(64)] = 1
+    nn = mn.MnistNN(64, colsum_mode=mn.COLSUM_INTENDED)
+    ref = mn.MnistNN(64, colsum_mode=mn.COLSUM_INTENDED)
+    for t in (nn, ref):
+        t.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]]); t.load_batch(x_raw, y)
+    for _ in range(3):
+        ex = mn.Exchange(0, 1, nn.count)
+        nn.dp_step(ex); nn.dp_step(ex)
+        assert ex.status() == 0
+        ex.close()
+        ref.train_step(); ref.train_step()
+    np.testing.assert_allclose(mn.flatten_params(nn.get_params()), mn.flatten_params(ref.get_params()), rtol=1e-6, atol=1e-7)
+
+
+def test_rccl_step_single_rank_equals_train_step(dev):
+    """C-ABI RCCL path (bla_dp_rccl_*, bla_mnist_nn_dp_step_rccl) with world = 1: ncclAllReduce over one rank is the identity, so the
+    step must equal bla_mnist_nn_train_step bit for bit (same kernels, same order)."""
+    mn = dev.mnist_nn
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mnist_nn_params.npz"))
+    x_raw = randint(7, (784, 256), 256).astype(np.float32)
+    lab = randint(8, (256,), 10); y = np.zeros((10, 256), np.float32); y[lab, np.arange(256)] = 1
+    comm = mn.RcclComm(0, 1)
+    outs = []
+    for mode in ("rccl", "plain"):
+        nn = mn.MnistNN(256, colsum_mode=mn.COLSUM_INTENDED)
+        nn.set_params([z[n] for n in ["w1", "b1", "w2", "b2", "w3", "b3"]])
+        nn.load_batch(x_raw, y)
+        for _ in range(4):
+            nn.dp_step_rccl(comm) if mode == "rccl" else nn.train_step()
+        outs.append(mn.flatten_params(nn.get_params()))
+    comm.close()
+    assert np.array_equal(outs[0], outs[1])
+    # and the raw collective: in place, SUM, one rank
+    g = dev.to_device(uniform(5, (10007,), -1, 1, np.float32))
+    comm = mn.RcclComm(0, 1)
+    comm.allreduce(g.ptr, 10007); dev.sync()
+    assert np.array_equal(g.numpy(), uniform(5, (10007,), -1, 1, np.float32))
+    comm.close()
 
 
 def test_single_rank_exchange_is_the_plain_step(dev):
