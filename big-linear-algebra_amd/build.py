@@ -81,7 +81,9 @@ def build_hip(force=False, verbose=False):
 
 
 def build_host(force=False):
-    srcs = sorted(glob.glob(os.path.join(HOST, "*.c")))
+    # lib/mnist_csv.c (legacy streaming reader) and lib/mnist_csv2.c define the same names by the reference's design: like the reference's
+    # build, a program links one of them; the shared library carries mnist_csv2 (what model/mnist_nn.c uses)
+    srcs = sorted(f for f in glob.glob(os.path.join(HOST, "*.c")) if os.path.basename(f) != "mnist_csv.c")
     if not srcs:
         return None
     hdrs = glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))

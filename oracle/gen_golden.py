@@ -512,6 +512,138 @@ def gen_resnet():
     np.savez_compressed(os.path.join(GOLD, "resnet.npz"), **d)
 
 
+# ---- lib/layer.c through the reference itself -----------------------------------------------------------------
+class RefLayer(C.Structure):
+    """struct Layer, lib/layer.h:4-15 (reference build: Matrix.data is double*)."""
+
+
+RefLayer._fields_ = [("num_nodes", C.c_int), ("nodes", ref.PM), ("raw_nodes", ref.PM), ("weights", ref.PM), ("biases", ref.PM),
+                     ("previous_layer", C.POINTER(RefLayer)), ("activation", C.c_void_p), ("activation_ddx", C.c_void_p),
+                     ("has_previous_layer", C.c_char), ("has_nodes", C.c_char)]
+# the reference declares the callbacks void(*)(float*, int) and hands them Matrix.data, which is double* in its own build (Q4):
+# the harness's callbacks take the pointer for what it is
+ACT64 = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
+
+
+def ref_layer_net(sizes, weights, biases, x, act, act_ddx, expectations, lr):
+    """Builds the chain input -> ... -> output the way main.c:52-73 does, runs feed_forward on every non-input layer and then
+    back_propagate_errors on the output layer; returns per layer (nodes, raw_nodes) after the forward pass and (weights, biases)
+    after the update.  Matrices are made with the reference's make_matrix on malloc'd buffers (free_layer_data releases them)."""
+    libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    L.make_matrix.restype = ref.PM; L.make_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.feed_forward.argtypes = [C.POINTER(RefLayer)]
+    L.back_propagate_errors.argtypes = [C.POINTER(RefLayer), C.POINTER(C.c_float), C.c_float]
+    L.free_layer_data.argtypes = [RefLayer]
+
+    def heap(a):
+        a = np.ascontiguousarray(a, np.float64)
+        p = libc.malloc(a.nbytes); C.memmove(p, a.ctypes.data, a.nbytes)
+        return L.make_matrix(a.shape[0], a.shape[1], C.cast(p, C.POINTER(C.c_double)))
+    fa, fd = ACT64(act), ACT64(act_ddx)
+    layers = [RefLayer(sizes[0], heap(x), None, None, None, None, None, None, b"\x00", b"\x01")]
+    for i in range(1, len(sizes)):
+        layers.append(RefLayer(sizes[i], None, None, heap(weights[i - 1]), heap(biases[i - 1]), C.pointer(layers[i - 1]),
+                               C.cast(fa, C.c_void_p), C.cast(fd, C.c_void_p), b"\x01", b"\x00"))
+    for l in layers[1:]:
+        L.feed_forward(C.byref(l))
+    arr = lambda pm: np.ctypeslib.as_array(pm.contents.data, shape=(pm.contents.rows, pm.contents.cols)).copy()
+    fwd = [(arr(l.nodes), arr(l.raw_nodes)) for l in layers[1:]]
+    e = np.ascontiguousarray(expectations, np.float32)
+    L.back_propagate_errors(C.byref(layers[-1]), e.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(lr))
+    upd = [(arr(l.weights), arr(l.biases)) for l in layers[1:]]
+    for l in reversed(layers[1:]):
+        L.free_layer_data(l)
+    L.free_matrix(layers[0].nodes)
+    return fwd, upd
+
+
+def gen_layer():
+    """lib/layer.c:6-107.  Case "main": main.c:52-87 verbatim (3-2-2 net from data/inputs.csv, weights.csv, biases.csv -- the output
+    layer loads the same files, i.e. the first 4 weights; activation x0.1, derivative 0.1, expectations {0.5, 0.5}, lr 0.05).
+    Case "mlp": 12-7-5-3 net, leaky-ReLU-like callbacks, random values."""
+    d = {}
+
+    def act_main(p, n):
+        for i in range(n):
+            p[i] *= 0.1
+
+    def ddx_main(p, n):
+        for i in range(n):
+            p[i] = 0.1
+    x = read_csv(f"{REFROOT}/data/inputs.csv", 3).astype(np.float64).reshape(3, 1)
+    wv = read_csv(f"{REFROOT}/data/weights.csv", 6).astype(np.float64)
+    bv = read_csv(f"{REFROOT}/data/biases.csv", 2).astype(np.float64)
+    ws = [wv.reshape(2, 3), wv[:4].reshape(2, 2)]; bs = [bv.reshape(2, 1), bv.reshape(2, 1)]
+    fwd, upd = ref_layer_net([3, 2, 2], ws, bs, x, act_main, ddx_main, [0.5, 0.5], 0.05)
+    for f in ("inputs", "weights", "biases"):      # the data files themselves (data, not source): the host-layer test loads them through load_*_from_csv
+        d[f"main_{f}_csv"] = np.frombuffer(open(f"{REFROOT}/data/{f}.csv", "rb").read(), np.uint8)
+    d["main_x"] = x; d["main_lr"] = np.array(np.float32(0.05), np.float64); d["main_expect"] = np.array([0.5, 0.5])
+    for i in range(2):
+        d[f"main_w{i}"], d[f"main_b{i}"] = ws[i], bs[i]
+        d[f"main_nodes{i}"], d[f"main_raw{i}"] = fwd[i]
+        d[f"main_w{i}_new"], d[f"main_b{i}_new"] = upd[i]
+
+    def act_leaky(p, n):
+        for i in range(n):
+            if p[i] < 0:
+                p[i] *= 0.25
+
+    def ddx_leaky(p, n):
+        for i in range(n):
+            p[i] = 1.0 if p[i] > 0 else 0.25
+    sizes = [12, 7, 5, 3]
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)          # fp32-representable inputs: the device build holds exactly these
+    ws = [f32(uniform(9100 + i, (sizes[i + 1], sizes[i]), -0.7, 0.7)) for i in range(3)]
+    bs = [f32(uniform(9200 + i, (sizes[i + 1], 1), -0.3, 0.3)) for i in range(3)]
+    x = f32(uniform(9300, (12, 1), -1, 1)); e = f32(uniform(9301, (3,), 0, 1))
+    fwd, upd = ref_layer_net(sizes, ws, bs, x, act_leaky, ddx_leaky, e, 0.125)
+    d["mlp_sizes"] = np.array(sizes, np.int64); d["mlp_x"] = x; d["mlp_expect"] = e; d["mlp_lr"] = np.array(0.125)
+    for i in range(3):
+        d[f"mlp_w{i}"], d[f"mlp_b{i}"] = ws[i], bs[i]
+        d[f"mlp_nodes{i}"], d[f"mlp_raw{i}"] = fwd[i]
+        d[f"mlp_w{i}_new"], d[f"mlp_b{i}_new"] = upd[i]
+    np.savez_compressed(os.path.join(GOLD, "layer.npz"), **d)
+
+
+def capture_stdout(fn):
+    """Runs fn() with file descriptor 1 pointing at a temporary file; returns the bytes the C library wrote."""
+    import tempfile
+    libc = C.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    with tempfile.TemporaryFile() as tmp:
+        saved = os.dup(1)
+        os.dup2(tmp.fileno(), 1)
+        try:
+            fn(); libc.fflush(None)
+        finally:
+            os.dup2(saved, 1); os.close(saved)
+        tmp.seek(0)
+        return tmp.read()
+
+
+def gen_print():
+    """print_matrix / print_matrix_dim, lib/matrix.c:71-93: the reference's own stdout for matrices that hit every branch -- exact zero,
+    negative values (all of which fall into the `< 0.01` branch and print as %.2e), small positives, values >= 0.01 -- and the
+    two error messages that precede exit(1) are pinned in tests/c/host_errors.c.  Values are fp32-representable, so the float build
+    prints the same digits."""
+    L.print_matrix.argtypes = [ref.Matrix]; L.print_matrix_dim.argtypes = [ref.Matrix]
+    mats_ = {
+        "zeros": np.zeros((2, 3)),
+        "mixed": np.array([[0.0, -3.25, 0.0078125, 0.5], [1234.5, -0.001953125, 0.015625, 100.0], [0.009765625, 0.25, -1e3, 2.0 ** -20]]),
+        "main_kat": ref.matmul(np.array([[1, 2, 3], [4, 5, 6]], np.float64), np.array([[1, 0.5], [0.25, 1], [0, 2]], np.float64)),
+        "column": np.array([[2.5], [-0.125], [0.0]]),
+        "row": np.array([[0.01171875, 7.0, 65536.0, -65536.0]]),
+    }
+    d = {}
+    for name, a in mats_.items():
+        a = np.ascontiguousarray(a, np.float64)
+        assert np.array_equal(a.astype(np.float32).astype(np.float64), a), name
+        m = ref.mat(a)
+        d[name] = a
+        d[name + "__stdout"] = np.frombuffer(capture_stdout(lambda: (L.print_matrix(m), L.print_matrix_dim(m))), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "print_matrix.npz"), **d)
+
+
 def sum_seq(v):
     """left-to-right fp64 sum, the order of the loop at model/cifar_unet.c:1191-1196"""
     s_ = 0.0
@@ -523,6 +655,11 @@ def sum_seq(v):
 if __name__ == "__main__":
     assert ref.available(), "build oracle/_ref first: make -C oracle"
     os.makedirs(GOLD, exist_ok=True)
-    gen_gemm(); gen_matrix_ops(); gen_conv(); gen_norm(); gen_mnist(); gen_unet_glue(); gen_attention(); gen_resnet()
+    only = sys.argv[1:]          # e.g. `gen_golden.py layer print` regenerates just those files
+    gens = {"gemm": gen_gemm, "matrix_ops": gen_matrix_ops, "conv": gen_conv, "norm": gen_norm, "mnist": gen_mnist, "unet_glue": gen_unet_glue,
+            "attention": gen_attention, "resnet": gen_resnet, "layer": gen_layer, "print": gen_print}
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden vectors written to", GOLD, f"({tot/1e6:.2f} MB)")

@@ -314,6 +314,52 @@ def mnist_step(params, x_raw, y, colsum_intended=False):
     return ps, ad, gl
 
 
+# ---- lib/layer.c:6-107 (single-sample dense layers; small shapes: numpy over the restated products) ------------
+def layer_net(sizes, weights, biases, x, act, act_ddx, expectations, learn_rate):
+    """feed_forward on every non-input layer (lib/layer.c:6-20: raw = W.a_prev + b, nodes = act(raw)), then back_propagate_errors on the
+    output layer (:80-107) with its recursion toward the input (:48-78).  act / act_ddx work in place on a vector like the reference's
+    callbacks.  The reference passes learn_rate as a float and negates it as a float (:65,95).  Returns ([(nodes, raw)], [(W_new, b_new)])."""
+    dt = np.dtype(weights[0].dtype)
+    lr = dt.type(-np.float32(learn_rate))
+    a = [_c(x, dt).reshape(-1, 1)]; raw = [None]
+    for w, b in zip(weights, biases):
+        z = matmul(_c(w, dt), a[-1]) + _c(b, dt).reshape(-1, 1)          # matrix_multiply, matrix_add (:10-11)
+        raw.append(z.copy()); n = z.copy().ravel(); act(n); a.append(n.reshape(-1, 1))
+    n_layers = len(weights)
+    new = [None] * n_layers
+
+    def step(l, cost_ddx_act):
+        """layer index l (1-based): the shared tail of :64-77 / :92-106"""
+        d = raw[l].copy().ravel(); act_ddx(d); d = d.reshape(-1, 1)
+        db = hadamard(d, cost_ddx_act) * lr                               # matrix_multiply_elementwise, matrix_scale
+        dw = matmul(db, transpose(a[l - 1]))                              # transpose, multiply, transpose back
+        if l - 1 >= 1:                                                    # do_back_propagate_errors(previous, this, ...) with the OLD weights
+            g = raw[l].copy().ravel(); act_ddx(g); g = hadamard(g.reshape(-1, 1), cost_ddx_act)
+            step(l - 1, matmul(transpose(_c(weights[l - 1], dt)), g))
+        new[l - 1] = (_c(weights[l - 1], dt) + dw, _c(biases[l - 1], dt).reshape(-1, 1) + db)
+    e = _c(np.asarray(expectations, np.float32).astype(dt), dt).reshape(-1, 1)   # float* expectations (:80)
+    step(n_layers, 2 * (a[-1] - e))
+    return [(a[i], raw[i]) for i in range(1, n_layers + 1)], new
+
+
+def print_matrix_text(m):
+    """print_matrix + print_matrix_dim, lib/matrix.c:71-93, as the bytes the reference writes to stdout (C printf semantics: exact zero
+    -> "0 ", anything below 0.01 -- negatives included -- "%.2e ", the rest "%.2f ")."""
+    m = np.asarray(m)
+    out = ["%d x %d matrix\n" % m.shape]
+    flat = m.ravel()
+    for i, v in enumerate(flat):
+        v = float(v)
+        if i % m.shape[1] == 0:
+            out.append("[ ")
+        out.append("0 " if v == 0 else ("%.2e " % v if v < 0.01 else "%.2f " % v))
+        if (i + 1) % m.shape[1] == 0:
+            out.append("]\n")
+    out.append("\n")
+    out.append("%d x %d matrix\n" % m.shape)
+    return "".join(out).encode()
+
+
 # ---- error-bound helpers ------------------------------------------------------
 def matmul_f32_acc64(a, b):
     a, b = _c(a, np.float32), _c(b, np.float32)

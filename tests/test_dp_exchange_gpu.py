@@ -24,9 +24,9 @@ def dev():
 
 def run_ranks(world, tmp, steps, per, algo, ranks_per_process=1):
     """`world` ranks as world / ranks_per_process processes on the one GPU (the box allows 6 processes on the card: 8 ranks need
-    several ranks per process, each in its own bla context with its own stream -- GPU_MAX_HW_QUEUES gives every stream its own
+    several ranks per process, each in its own bla context with its own stream -- GPU_MAX_HW_QUEUES=16 gives every stream its own
     hardware queue so that the launches of one process's ranks run side by side, as they would on separate GPUs)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLA_DP_ALGO=algo, GPU_MAX_HW_QUEUES="8")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLA_DP_ALGO=algo, GPU_MAX_HW_QUEUES="16")
     if world > 4:
         env["BLA_DP_MAX_BLOCKS"] = "48"        # all ranks' spinning exchange launches and the gradient kernels they wait for share one GPU here
     procs = [subprocess.Popen([sys.executable, WORKER, str(lo), str(min(lo + ranks_per_process, world)), str(world), str(tmp), str(steps), str(per)],

@@ -79,6 +79,28 @@ def _cc(args, **kw):
     return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **kw)
 
 
+def test_print_matrix_stdout_matches_the_reference(host):
+    """print_matrix / print_matrix_dim (lib/matrix.c:71-93) write the same BYTES as the reference did for the same matrices
+    (tests/golden/print_matrix.npz holds the reference's captured stdout): exact zeros, negatives (which take the `< 0.01` branch and
+    print as %.2e), small positives, ordinary values, the 2 x 2 known answer of main.c:39-40.  Host-only: no device needed."""
+    import tempfile
+    g = golden("print_matrix")
+    host.print_matrix.argtypes = [Matrix]; host.print_matrix_dim.argtypes = [Matrix]
+    libc = C.CDLL(None)
+    for name in ("zeros", "mixed", "main_kat", "column", "row"):
+        a = np.ascontiguousarray(g[name], F32)
+        assert np.array_equal(a.astype(np.float64), g[name])       # fp32-representable by construction
+        sys.stdout.flush(); libc.fflush(None)
+        with tempfile.TemporaryFile() as tmp:
+            saved = os.dup(1); os.dup2(tmp.fileno(), 1)
+            try:
+                host.print_matrix(mat(a)); host.print_matrix_dim(mat(a)); libc.fflush(None)
+            finally:
+                os.dup2(saved, 1); os.close(saved)
+            tmp.seek(0); got = tmp.read()
+        assert got == bytes(g[name + "__stdout"].astype(np.uint8)), (name, got)
+
+
 def test_exports_reference_symbols(host):
     """Every function the reference headers declare (lib/matrix.h:13-32, conv.h:13-16, norm.h:6-7, util.h:7-11,
     layer.h:17-21, csv.h) plus the four extern helpers of lib/conv.c is exported."""
@@ -112,15 +134,15 @@ def test_error_behaviour_matches_reference(tmp_path, host):
 @pytest.mark.parametrize("prog,extra_ref,ours", [
     ("model/mnist_nn.c", [], ["matrix.c", "csv.c", "mnist_csv2.c", "bla_host.c"]),
     ("model/cifar_unet.c", [], ["matrix.c", "conv.c", "norm.c", "util.c", "csv.c", "cifar10.c", "bmp.c", "bla_host.c"]),
-    ("model/mnist_hinge.c", ["lib/mnist_csv.c"], ["matrix.c", "layer.c", "csv.c", "bla_host.c"]),
+    ("model/mnist_hinge.c", [], ["matrix.c", "layer.c", "csv.c", "mnist_csv.c", "bla_host.c"]),
     ("main.c", [], ["matrix.c", "layer.c", "csv.c", "bla_host.c"]),
     ("model/my_first_model.c", [], ["matrix.c", "layer.c", "csv.c", "bla_host.c"]),
 ])
 def test_reference_programs_link_unchanged(tmp_path, pkg, prog, extra_ref, ours):
     """The model sources are compiled where they are, from a scratch tree that lays our lib/ next to them
-    (they include "../lib/matrix.h").  mnist_nn.c, cifar_unet.c, main.c and my_first_model.c link against this
-    repo's units ONLY; mnist_hinge.c additionally takes the legacy streaming reader lib/mnist_csv.c from the
-    reference (not shipped here: it clashes with mnist_csv2.h by design)."""
+    (they include "../lib/matrix.h").  All five link against this repo's units ONLY (mnist_hinge.c takes the legacy
+    streaming reader lib/mnist_csv.c, which clashes with mnist_csv2.h by the reference's design and is therefore a
+    per-program unit here as there)."""
     pkg.build_native()
     tree = tmp_path / "tree"
     (tree / "model").mkdir(parents=True)
@@ -264,11 +286,7 @@ def test_norm_h_against_golden(host):
         assert (np.abs(dest - ref) <= 2e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max()).all()
 
 
-@gpu
-def test_layer_h_known_answer(host, tmp_path):
-    """main.c:52-87 (3-2-2 net, activation x0.1, derivative 0.1, lr 0.1): the reference built with an fp32 typedef
-    prints layer output [2.47; 5.39] and, after back-propagation, weights [0.91 1.80; 2.78 3.51], biases [0.08; 0.15]
-    (SURVEY section 4).  Rebuilt here from the same CSV values through the drop-in layer.h."""
+def _layer_types(host):
     class Layer(C.Structure):
         pass
     ACT = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int)
@@ -278,37 +296,105 @@ def test_layer_h_known_answer(host, tmp_path):
     host.make_matrix.restype = PM; host.make_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float)]
     host.feed_forward.argtypes = [C.POINTER(Layer)]
     host.back_propagate_errors.argtypes = [C.POINTER(Layer), C.POINTER(C.c_float), C.c_float]
+    host.free_layer_data.argtypes = [Layer]
+    host.load_weights_from_csv.argtypes = [C.POINTER(Layer), C.c_char_p]
+    host.load_biases_from_csv.argtypes = [C.POINTER(Layer), C.c_char_p]
+    host.read_csv_contents.restype = C.POINTER(C.c_float); host.read_csv_contents.argtypes = [C.c_char_p]
+    return Layer, ACT
+
+
+def _arr(pm):
+    return np.ctypeslib.as_array(pm.contents.data, shape=(pm.contents.rows, pm.contents.cols)).copy()
+
+
+@gpu
+def test_layer_h_main_c_known_answer(host, tmp_path):
+    """main.c:52-87 through the drop-in layer.h, against what the reference's own lib/layer.c computed (tests/golden/layer.npz, case
+    "main"): the 3-2-2 net is loaded from the reference's data files with load_weights_from_csv / load_biases_from_csv (both layers read
+    the same files, main.c:60-61,70-71), activation x0.1, derivative 0.1, expectations {0.5, 0.5}, learn rate 0.05; released with
+    free_layer_data like main.c:85-87.  SURVEY section 4: output [2.47; 5.39]; then weights [0.91 1.80; 2.78 3.51], biases [0.08; 0.15]."""
+    g = golden("layer")
+    Layer, ACT = _layer_types(host)
+    paths = {}
+    for f in ("inputs", "weights", "biases"):
+        paths[f] = str(tmp_path / f"{f}.csv")
+        with open(paths[f], "wb") as fh:
+            fh.write(bytes(g[f"main_{f}_csv"].astype(np.uint8)))
 
     @ACT
     def act(p, n):
         for i in range(n):
-            p[i] = p[i] * F32(0.1)
+            p[i] = float(p[i]) * 0.1          # data[i] *= 0.1 (main.c:9): double product, stored as float
 
     @ACT
     def act_ddx(p, n):
         for i in range(n):
             p[i] = 0.1
-    # data/inputs.csv, data/weights.csv, data/biases.csv of the reference (values only)
-    x = np.array([[1], [2], [3]], F32); w1 = np.array([[1, 2, 3], [4, 5, 6]], F32); b1 = np.array([[0.5], [0.5]], F32)
-    w2 = np.array([[1, 2], [3, 4]], F32); b2 = np.array([[0.1], [0.2]], F32)
+    inp = Layer(3, host.make_matrix(3, 1, host.read_csv_contents(paths["inputs"].encode())), None, None, None, None, act, act_ddx, b"\x00", b"\x01")
+    hid = Layer(2, None, None, None, None, C.pointer(inp), act, act_ddx, b"\x01", b"\x00")
+    outl = Layer(2, None, None, None, None, C.pointer(hid), act, act_ddx, b"\x01", b"\x00")
+    for l in (hid, outl):
+        host.load_weights_from_csv(C.byref(l), paths["weights"].encode())
+        host.load_biases_from_csv(C.byref(l), paths["biases"].encode())
+    host.load_weights_from_csv(C.byref(inp), paths["weights"].encode())       # input layer: a no-op (lib/layer.c:35-37)
+    assert not inp.weights
+    assert np.array_equal(_arr(hid.weights), g["main_w0"]) and np.array_equal(_arr(outl.weights), g["main_w1"])
+    assert np.array_equal(_arr(outl.biases), g["main_b1"].astype(F32))
+    host.feed_forward(C.byref(inp))                                            # no-op as well (:7-9)
+    host.feed_forward(C.byref(hid)); host.feed_forward(C.byref(outl))
+    tol = dict(rtol=2e-6, atol=0)
+    for i, l in enumerate((hid, outl)):
+        np.testing.assert_allclose(_arr(l.nodes), g[f"main_nodes{i}"], **tol)
+        np.testing.assert_allclose(_arr(l.raw_nodes), g[f"main_raw{i}"], **tol)
+    assert np.allclose(_arr(outl.nodes).ravel(), [2.47, 5.39], atol=5e-3)
+    e = g["main_expect"].astype(F32)
+    host.back_propagate_errors(C.byref(outl), e.ctypes.data_as(C.POINTER(C.c_float)), float(g["main_lr"]))
+    for i, l in enumerate((hid, outl)):
+        np.testing.assert_allclose(_arr(l.weights), g[f"main_w{i}_new"], **tol)
+        np.testing.assert_allclose(_arr(l.biases), g[f"main_b{i}_new"], **tol)
+    assert np.allclose(_arr(outl.weights).ravel(), [0.91, 1.80, 2.78, 3.51], atol=5e-3) and np.allclose(_arr(outl.biases).ravel(), [0.08, 0.15], atol=5e-3)
+    host.feed_forward(C.byref(hid))        # a second pass takes the has_nodes branch (frees only the structs, :12-15)
+    host.free_layer_data(outl); host.free_layer_data(hid); host.free_matrix(inp.nodes)
+
+
+@gpu
+def test_layer_h_mlp_against_reference_run(host):
+    """12-7-5-3 net, leaky-ReLU callbacks: feed_forward / back_propagate_errors / do_back_propagate_errors (lib/layer.c:6-107) against
+    the reference's own run (layer.npz case "mlp"), 1e-5 relative with an absolute floor of 1e-6 of the tensor's scale."""
+    g = golden("layer")
+    Layer, ACT = _layer_types(host)
     malloc = C.CDLL(None).malloc; malloc.restype = C.c_void_p; malloc.argtypes = [C.c_size_t]
 
     def heap(a):   # the library frees these with free(): they must come from malloc
+        a = np.ascontiguousarray(a, F32)
         p = malloc(a.nbytes); C.memmove(p, a.ctypes.data, a.nbytes)
         return host.make_matrix(a.shape[0], a.shape[1], C.cast(p, C.POINTER(C.c_float)))
-    inp = Layer(3, heap(x), None, None, None, None, act, act_ddx, b"\x00", b"\x01")
-    hid = Layer(2, None, None, heap(w1), heap(b1), C.pointer(inp), act, act_ddx, b"\x01", b"\x00")
-    outl = Layer(2, None, None, heap(w2), heap(b2), C.pointer(hid), act, act_ddx, b"\x01", b"\x00")
-    host.feed_forward(C.byref(hid)); host.feed_forward(C.byref(outl))
-    h_ref = 0.1 * (w1.astype(np.float64) @ x + b1); o_ref = 0.1 * (w2.astype(np.float64) @ h_ref + b2)
-    got = np.ctypeslib.as_array(outl.nodes.contents.data, shape=(2, 1))
-    assert np.allclose(got, o_ref, rtol=1e-6)
-    # one back-propagation step against a float64 evaluation of lib/layer.c:48-107
-    y = np.array([1.0, 0.0], F32); lr = 0.1
-    g_out = 2 * (o_ref - y.reshape(2, 1)); d2 = 0.1 * g_out * -lr; dW2 = d2 @ h_ref.T
-    g_hid = w2.astype(np.float64).T @ (0.1 * g_out); d1 = 0.1 * g_hid * -lr; dW1 = d1 @ x.astype(np.float64).T
-    host.back_propagate_errors(C.byref(outl), y.ctypes.data_as(C.POINTER(C.c_float)), lr)
-    assert np.allclose(np.ctypeslib.as_array(outl.weights.contents.data, shape=(2, 2)), w2 + dW2, rtol=2e-6)
-    assert np.allclose(np.ctypeslib.as_array(outl.biases.contents.data, shape=(2, 1)), b2 + d2, rtol=2e-6)
-    assert np.allclose(np.ctypeslib.as_array(hid.weights.contents.data, shape=(2, 3)), w1 + dW1, rtol=2e-6)
-    assert np.allclose(np.ctypeslib.as_array(hid.biases.contents.data, shape=(2, 1)), b1 + d1, rtol=2e-6)
+
+    @ACT
+    def act(p, n):
+        for i in range(n):
+            if p[i] < 0:
+                p[i] = p[i] * 0.25
+
+    @ACT
+    def act_ddx(p, n):
+        for i in range(n):
+            p[i] = 1.0 if p[i] > 0 else 0.25
+    sizes = [int(v) for v in g["mlp_sizes"]]
+    layers = [Layer(sizes[0], heap(g["mlp_x"]), None, None, None, None, act, act_ddx, b"\x00", b"\x01")]
+    for i in range(1, 4):
+        layers.append(Layer(sizes[i], None, None, heap(g[f"mlp_w{i-1}"]), heap(g[f"mlp_b{i-1}"]), C.pointer(layers[i - 1]), act, act_ddx, b"\x01", b"\x00"))
+    for l in layers[1:]:
+        host.feed_forward(C.byref(l))
+
+    def close(got, ref):
+        return (np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-6 * np.abs(ref).max()).all()
+    for i, l in enumerate(layers[1:]):
+        assert close(_arr(l.nodes), g[f"mlp_nodes{i}"]) and close(_arr(l.raw_nodes), g[f"mlp_raw{i}"]), i
+    e = g["mlp_expect"].astype(F32)
+    host.back_propagate_errors(C.byref(layers[-1]), e.ctypes.data_as(C.POINTER(C.c_float)), float(g["mlp_lr"]))
+    for i, l in enumerate(layers[1:]):
+        assert close(_arr(l.weights), g[f"mlp_w{i}_new"]) and close(_arr(l.biases), g[f"mlp_b{i}_new"]), i
+    for l in reversed(layers[1:]):
+        host.free_layer_data(l)
+    host.free_matrix(layers[0].nodes)

@@ -128,3 +128,57 @@ def test_bmp_and_cifar_match_reference(ours, theirs, tmp_path):
         # byte 47 (info header [33]) is never written by the reference (lib/bmp.c:70-72 assigns [32] twice): stack garbage there
         assert files[0][:47] == files[1][:47] and files[0][48:] == files[1][48:]
         assert files[0][:2] == b"BM" and len(files[0]) == 54 + ((24 * w + 31) // 32) * 4 * h
+
+
+def _legacy_reader(path_c, tmp):
+    """lib/mnist_csv.c is a per-program unit (it clashes with mnist_csv2.c by the reference's design): build it alone."""
+    so = str(tmp / (os.path.basename(os.path.dirname(os.path.dirname(path_c))) + "_legacy.so"))
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-w", "-fPIC", "-shared", "-o", so, path_c])
+    L = C.CDLL(so)
+    return L
+
+
+class LegacyCSV(C.Structure):
+    _fields_ = [("file", C.c_void_p), ("buffer", C.POINTER(C.c_float)), ("num_lines", C.c_int)]
+
+
+def _legacy_rows(L, path, rows, tmp, tag):
+    """get_next_data x rows (+ one call past the end), visualize_digit_data of the last row; returns (values, return codes, stdout)."""
+    fopen = libc.fopen; fopen.restype = C.c_void_p
+    libc.fclose.argtypes = [C.c_void_p]; libc.fflush.argtypes = [C.c_void_p]; libc.fgetc.argtypes = [C.c_void_p]
+    buf = np.zeros(785, np.float32)
+    csv = LegacyCSV(fopen(path.encode(), b"r"), buf.ctypes.data_as(C.POINTER(C.c_float)), rows)
+    L.get_next_data.argtypes = [C.POINTER(LegacyCSV)]; L.visualize_digit_data.argtypes = [C.POINTER(LegacyCSV)]
+    out_path = str(tmp / f"{tag}.txt")
+    libc.fflush(None)
+    saved = os.dup(1); fd = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC); os.dup2(fd, 1)
+    vals, rcs = [], []
+    try:
+        for _ in range(rows):
+            rcs.append(L.get_next_data(C.byref(csv))); vals.append(buf.copy())
+        buf[1:] /= 255.0                                  # callers normalise before drawing (model/mnist_hinge.c)
+        L.visualize_digit_data(C.byref(csv))
+        libc.fgetc(csv.file)                              # the reference tests feof(), which needs a read past the end first
+        rcs.append(L.get_next_data(C.byref(csv)))
+        libc.fflush(None)
+    finally:
+        os.dup2(saved, 1); os.close(saved); os.close(fd)
+    libc.fclose(csv.file)
+    return np.array(vals), rcs, open(out_path, "rb").read()
+
+
+def test_legacy_streaming_reader_matches_reference(tmp_path):
+    """lib/mnist_csv.c (get_next_data, visualize_digit_data): same values, same return codes, same stdout as the reference's unit
+    on a synthetic MNIST-shaped file (label + 784 pixels per row, comma-terminated values, newline-terminated rows)."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference sources only exist in the build container")
+    rng = np.random.default_rng(3)
+    rows = 4
+    path = str(tmp_path / "mnist.csv")
+    with open(path, "w") as f:
+        for r in range(rows):
+            f.write(",".join(str(int(v)) for v in [rng.integers(10)] + list(rng.integers(0, 256, 784))) + ("\n" if r % 2 else ",\n"))
+    mine = _legacy_rows(_legacy_reader(os.path.join(LIB, "mnist_csv.c"), tmp_path), path, rows, tmp_path, "ours")
+    ref = _legacy_rows(_legacy_reader(os.path.join(REF, "lib", "mnist_csv.c"), tmp_path), path, rows, tmp_path, "theirs")
+    assert np.array_equal(mine[0], ref[0]) and mine[1] == ref[1] == [0] * rows + [1]
+    assert mine[2] == ref[2] and b"CSV file is empty" in mine[2] and mine[2].count(b"\n") >= 31
