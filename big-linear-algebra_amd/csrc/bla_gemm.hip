@@ -60,6 +60,7 @@ struct GemmArgs {
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
 	int rc_global;   // host-side only: pick the instantiation that fetches row-contiguous operands with global_load_lds
+	int wsk_tile;    // wave-split-K kernels: 32 (32x32 tiles, MFMA 32x32x2) or 16 (16x16 tiles, MFMA 16x16x4)
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
@@ -1024,33 +1025,50 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 // once at the end and are summed in wave order (deterministic), and the epilogue is fused -- no slab
 // kernel, no second launch.  K-contiguous operands load 16 B per lane (row l&31, k-half l>>5),
 // row-contiguous operands four coalesced dwords per lane.
-constexpr int kWskLdsFloats = 4 * 2 * 2 * 32 * 32;   // [wave][set][operand][32 k][32]
+constexpr int kWskLdsFloats = 4 * 2 * 2 * 32 * 32;   // [wave][set][operand][k of a half-chunk][T] (32 k x 32 or 64 k x 16)
 struct WskShared {   // the LDS of one workgroup, declared once by the kernel (the pair kernel runs either body on it)
 	float smem[kWskLdsFloats];
 	float red_rs[4][64];
 	int is_last;
 };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int T> struct WskAcc { typedef f32x16 type; };
+template <> struct WskAcc<16> { typedef f32x4 type; };
 
+// T = 32: one 32x32 tile per workgroup on v_mfma_f32_32x32x2_f32 (lane l: index l&31, k-slot l>>5, 8 k per load group).
+// T = 16: one 16x16 tile per workgroup on v_mfma_f32_16x16x4_f32 (lane l: index l&15, k-slot l>>4, 16 k per load group): four times the
+// workgroups for the same product -- the MNIST-NN layers give 8-64 tiles of 32x32 on a 256-CU chip, and every workgroup then moves half
+// the operand bytes through its CU's memory queue, which is what bounds these launches (DESIGN 3.1 "latency-bound shapes").
+// In both shapes a lane holds 4 consecutive k of its row / column (one 16-byte load) and MFMA j of a group multiplies element j of every
+// lane, i.e. k = {group base + 4*slot + j}: the groups' k are permuted against the reference's ascending order, each is used once.
 // bx = tile index (row-major over tiles_m x tiles_n), by = K-split index (0 when splits == 1)
-template <bool AKC, bool BKC, bool AVEC, bool BVEC>
+template <int T, bool AKC, bool BKC, bool AVEC, bool BVEC>
 __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by, WskShared& sh) {
 	constexpr int NW = 4;  // one wave per SIMD: a CU retires 256 fp32-MFMA FLOP/clk however many waves it hosts (8 / 16 measured slower)
-	constexpr int PF = 4;  // k-groups (8 k each) per half-chunk = 32 k; two half-chunks (register sets) are in flight
-	// One LDS array: per-wave staging of row-contiguous operands during the K loop ([wave][set][operand][32 k][32]),
+	constexpr int PF = 4;  // load groups per half-chunk; two half-chunks (register sets) are in flight
+	constexpr int QN = 64 / T;       // k-slots: lanes that share a row / column index
+	constexpr int GK = 4 * QN;       // k per load group (8 or 16)
+	constexpr int KH = GK * PF;      // k per half-chunk (32 or 64)
+	constexpr int TT = T * T, RS = T + 1;
+	constexpr int SEG = T / 4;       // lanes per staged row segment (16 bytes each)
+	constexpr int RPI = 64 / SEG;    // k-rows one staging instruction covers (8 or 16); KH / RPI == PF
+	typedef typename WskAcc<T>::type acc_t;
+	constexpr int NR = T == 32 ? 16 : 4;
+	// One LDS array: per-wave staging of row-contiguous operands during the K loop ([wave][set][operand][KH k][T]),
 	// the cross-wave reduction afterwards.
 	float* smem = sh.smem;
-	float (*red)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem);
+	float* red = smem;                 // [wave][T][RS]
 	float (*red_rs)[64] = sh.red_rs;
 	int& is_last = sh.is_last;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int l31 = lane & 31, h = lane >> 5;
+	const int li = lane & (T - 1), h = lane / T;
 	const int tile_m = bx / p.tiles_n, tile_n = bx % p.tiles_n;
-	const int m0 = tile_m * 32, n0 = tile_n * 32;
-	const int kw = p.k_per_split;  // per-wave K extent, multiple of 8; a workgroup covers 4*kw, by selects which
+	const int m0 = tile_m * T, n0 = tile_n * T;
+	const int kw = p.k_per_split;  // per-wave K extent, multiple of GK; a workgroup covers 4*kw, by selects which
 	const int blk_end = min(p.K, (by + 1) * NW * kw);
 	const int k_begin = min(blk_end, (by * NW + wave) * kw), k_end = min(blk_end, k_begin + kw);
-	const int arow = min(m0 + l31, p.M - 1), bcol = min(n0 + l31, p.N - 1);  // clamped: out-of-range rows/cols are never stored
-	float* stage = smem + wave * (2 * 2 * 32 * 32);   // [set][operand][32 k][32]
+	const int arow = min(m0 + li, p.M - 1), bcol = min(n0 + li, p.N - 1);  // clamped: out-of-range rows/cols are never stored
+	float* stage = smem + wave * (2 * 2 * KH * T);   // [set][operand][KH k][T]
 
 	// K-contiguous operand (row r of X, 4 consecutive k per lane): 16 B per lane when aligned
 	auto load_kc = [&](const float* X, int ld, int r, bool vec, int k, float (&f)[4]) {
@@ -1070,21 +1088,21 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 #pragma unroll
 		for (int j = 0; j < 4; j++) { float x = X[(size_t)min(kb + j, p.K - 1) * ld + r]; f[j] = kb + j < k_end ? x : 0.f; }
 	};
-	// Row-contiguous operand, aligned: the wave fetches the whole 64 x 32 chunk with 8 x 16-byte loads per lane (8 lanes
-	// cover a 128-byte row segment; 32 k per half-chunk) into its private LDS slab, then every lane picks its fragment dwords from there.
+	// Row-contiguous operand, aligned: the wave fetches the whole KH x T chunk with PF x 16-byte loads per lane (SEG lanes
+	// cover one row segment) into its private LDS slab, then every lane picks its fragment dwords from there.
 	// 4x fewer vector-memory instructions than the dword form -- the texture addresser, not the MFMA pipe, bounds these kernels.
 	auto stage_rc = [&](const float* X, int ld, int r0, int rdim, int k, float* stage) {
-		const int c4 = (lane & 7) * 4, kr = lane >> 3;
+		const int c4 = (lane % SEG) * 4, kr = lane / SEG;
 		float4 v[PF];
 #pragma unroll
 		for (int i = 0; i < PF; i++) {
-			int kk = k + i * 8 + kr;
+			int kk = k + i * RPI + kr;
 			bool ok = kk < k_end && r0 + c4 < rdim;
 			float4 x = *reinterpret_cast<const float4*>(X + (size_t)min(kk, p.K - 1) * ld + min(r0 + c4, rdim - 4));
 			v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 #pragma unroll
-		for (int i = 0; i < PF; i++) *reinterpret_cast<float4*>(stage + (i * 8 + kr) * 32 + c4) = v[i];
+		for (int i = 0; i < PF; i++) *reinterpret_cast<float4*>(stage + (i * RPI + kr) * T + c4) = v[i];
 	};
 
 #ifdef BLA_WSK_DIAG   // diagnostics build only (tools/wsk_stamps.py): s_memtime stamps of workgroup 0, wave 0
@@ -1093,38 +1111,38 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 #define BLA_STAMP(i) do {} while (0)
 #endif
 	BLA_STAMP(0);
-	f32x16 acc;
+	acc_t acc;
 #pragma unroll
-	for (int r = 0; r < 16; r++) acc[r] = 0.f;
+	for (int r = 0; r < NR; r++) acc[r] = 0.f;
 	float rs = 0.f;   // this lane's share of sum_k A[row][k] (fused bias gradient)
 	const bool want_rs = p.row_sum_a != nullptr && tile_n == 0;
-	// Half-chunks of PF k-groups (32 k), software-pipelined over two register sets: the loads of half-chunk t+1 are issued
+	// Half-chunks of PF load groups, software-pipelined over two register sets: the loads of half-chunk t+1 are issued
 	// before the MFMAs of half-chunk t, so from the second half-chunk on the 1,000-3,000-cycle operand latency (measured
 	// with s_memtime stamps) hides under 16 MFMAs instead of adding to them.
 	auto fetch = [&](int k, int set, float (&fa)[PF][4], float (&fb)[PF][4]) {      // issue the loads of one half-chunk
-		float* st_a = stage + (set * 2 + 0) * 32 * 32;
-		float* st_b = stage + (set * 2 + 1) * 32 * 32;
+		float* st_a = stage + (set * 2 + 0) * KH * T;
+		float* st_b = stage + (set * 2 + 1) * KH * T;
 		if (!AKC && AVEC) stage_rc(p.A, p.lda, m0, p.M, k, st_a);
 		if (!BKC && BVEC) stage_rc(p.B, p.ldb, n0, p.N, k, st_b);
 #pragma unroll
 		for (int g = 0; g < PF; g++) {
-			if (AKC) load_kc(p.A, p.lda, arow, AVEC, k + 8 * g, fa[g]);
-			else if (!AVEC) load_rc_scalar(p.A, p.lda, arow, k + 8 * g, fa[g]);
-			if (BKC) load_kc(p.B, p.ldb, bcol, BVEC, k + 8 * g, fb[g]);
-			else if (!BVEC) load_rc_scalar(p.B, p.ldb, bcol, k + 8 * g, fb[g]);
+			if (AKC) load_kc(p.A, p.lda, arow, AVEC, k + GK * g, fa[g]);
+			else if (!AVEC) load_rc_scalar(p.A, p.lda, arow, k + GK * g, fa[g]);
+			if (BKC) load_kc(p.B, p.ldb, bcol, BVEC, k + GK * g, fb[g]);
+			else if (!BVEC) load_rc_scalar(p.B, p.ldb, bcol, k + GK * g, fb[g]);
 		}
 	};
 	auto consume = [&](int set, float (&fa)[PF][4], float (&fb)[PF][4]) {           // fragments from LDS (staged operands), then MFMAs
 		if ((!AKC && AVEC) || (!BKC && BVEC)) {
-			const float* st_a = stage + (set * 2 + 0) * 32 * 32;
-			const float* st_b = stage + (set * 2 + 1) * 32 * 32;
+			const float* st_a = stage + (set * 2 + 0) * KH * T;
+			const float* st_b = stage + (set * 2 + 1) * KH * T;
 			__builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; this only pins the compiler's order
 #pragma unroll
 			for (int g = 0; g < PF; g++)
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
-					if (!AKC && AVEC) fa[g][j] = st_a[(8 * g + 4 * h + j) * 32 + l31];
-					if (!BKC && BVEC) fb[g][j] = st_b[(8 * g + 4 * h + j) * 32 + l31];
+					if (!AKC && AVEC) fa[g][j] = st_a[(GK * g + 4 * h + j) * T + li];
+					if (!BKC && BVEC) fb[g][j] = st_b[(GK * g + 4 * h + j) * T + li];
 				}
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -1135,11 +1153,13 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 #pragma unroll
 		for (int g = 0; g < PF; g++)
 #pragma unroll
-			for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
+			for (int j = 0; j < 4; j++) {
+				if constexpr (T == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
+				else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g][j], fb[g][j], acc, 0, 0, 0);
+			}
 	};
 	{
 		float fa0[PF][4], fb0[PF][4], fa1[PF][4], fb1[PF][4];
-		constexpr int KH = 8 * PF;
 		if (k_begin < k_end) fetch(k_begin, 0, fa0, fb0);
 		for (int k = k_begin; k < k_end; k += 2 * KH) {
 			if (k + KH < k_end) fetch(k + KH, 1, fa1, fb1);
@@ -1153,17 +1173,29 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 	BLA_STAMP(20);
 	__syncthreads();   // every wave is done with its staging slabs before they are reused as the reduction buffer
 	BLA_STAMP(21);
-	// partial tiles -> LDS (stride 33: the C/D map writes 32 consecutive columns per register), sum in wave order
+	// partial tiles -> LDS (stride T+1: the C/D map writes T consecutive columns per register), sum in wave order
 #pragma unroll
-	for (int r = 0; r < 16; r++) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+	for (int r = 0; r < NR; r++) {
+		const int row = T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * h : 4 * h + r;
+		red[wave * (T * RS) + row * RS + li] = acc[r];
+	}
 	if (want_rs) red_rs[wave][lane] = rs;
 	__syncthreads();
-	if (want_rs && tid < 32 && m0 + tid < p.M) {
+	if (want_rs && tid < T && m0 + tid < p.M) {
 		float t = 0.f;
 #pragma unroll
-		for (int w = 0; w < NW; w++) t += red_rs[w][tid] + red_rs[w][tid + 32];
+		for (int w = 0; w < NW; w++)
+#pragma unroll
+			for (int qq = 0; qq < QN; qq++) t += red_rs[w][tid + T * qq];
 		p.row_sum_a[m0 + tid] = p.rs_beta != 0.f ? p.rs_beta * p.row_sum_a[m0 + tid] + p.rs_alpha * t : p.rs_alpha * t;
 	}
+	auto fold = [&](int e) {   // element e of the tile, partials of the four waves added in wave order
+		const int r = e / T, c = e % T;
+		float s = 0.f;
+#pragma unroll
+		for (int w = 0; w < NW; w++) s += red[w * (T * RS) + r * RS + c];
+		return s;
+	};
 	if (p.splits > 1) {
 		// K is also cut over by (few tiles, long K: otherwise most CUs idle).  Each workgroup publishes its partial
 		// tile, draws a ticket on the tile's counter, and the LAST arriver folds the partials in split order (deterministic)
@@ -1171,13 +1203,8 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 		// reduction": plain stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 agent release fence -> vmcnt(0) ->
 		// relaxed agent fetch_add; last arriver: agent acquire fence -> vmcnt(0) -> barrier -> plain loads.  Correct for any
 		// placement of a tile's workgroups over CUs / XCDs.
-		float* mine = p.slab + ((size_t)bx * p.splits + by) * 1024;
-		for (int e = tid; e < 1024; e += NW * 64) {
-			float s = 0.f;
-#pragma unroll
-			for (int w = 0; w < NW; w++) s += red[w][(e >> 5) * 33 + (e & 31)];
-			mine[e] = s;
-		}
+		float* mine = p.slab + ((size_t)bx * p.splits + by) * TT;
+		for (int e = tid; e < TT; e += NW * 64) mine[e] = fold(e);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (tid == 0) {
@@ -1193,66 +1220,68 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 		}
 		__syncthreads();
 		if (!is_last) return;
-		const float* all = p.slab + (size_t)bx * p.splits * 1024;
-		for (int e = tid; e < 1024; e += NW * 64) {
-			int r = e >> 5, c = e & 31;
+		const float* all = p.slab + (size_t)bx * p.splits * TT;
+		for (int e = tid; e < TT; e += NW * 64) {
+			int r = e / T, c = e % T;
 			float s = 0.f;
-			for (int z = 0; z < p.splits; z++) s += all[(size_t)z * 1024 + e];
+			for (int z = 0; z < p.splits; z++) s += all[(size_t)z * TT + e];
 			if (m0 + r < p.M && n0 + c < p.N) epilogue_store(p, m0 + r, n0 + c, s);
 		}
 		return;
 	}
 	if (p.softmax_grad == nullptr) {
-		for (int e = tid; e < 1024; e += NW * 64) {
-			int r = e >> 5, c = e & 31;
-			float s = 0.f;
-#pragma unroll
-			for (int w = 0; w < NW; w++) s += red[w][r * 33 + c];
+		for (int e = tid; e < TT; e += NW * 64) {
+			int r = e / T, c = e % T;
+			float s = fold(e);
 			if (m0 + r < p.M && n0 + c < p.N) epilogue_store(p, m0 + r, n0 + c, s);
 		}
 		return;
 	}
-	// fused tail for the output layer (M <= 32: this tile holds whole columns): Z = alpha*acc + bias -> pre_act,
+	// fused tail for the output layer (M <= T: this tile holds whole columns): Z = alpha*acc + bias -> pre_act,
 	// P = softmax over the rows of each column -> C, grad = (P - Y) * scale        (model/mnist_nn.c:231-234,260-268)
-	for (int e = tid; e < 1024; e += NW * 64) {
-		int r = e >> 5, c = e & 31;
-		float s = 0.f;
-#pragma unroll
-		for (int w = 0; w < NW; w++) s += red[w][r * 33 + c];
+	for (int e = tid; e < TT; e += NW * 64) {
+		int r = e / T, c = e % T;
+		float s = fold(e);
 		s *= p.alpha;
 		if (p.bias_row && r < p.M) s += p.bias_row[r];
-		red[0][r * 33 + c] = s;   // element e is read and rewritten by this thread only: no barrier needed here
+		red[r * RS + c] = s;   // element e is read and rewritten by this thread only: no barrier needed here
 		if (p.pre_act && r < p.M && n0 + c < p.N) p.pre_act[(size_t)r * p.ld_pre + n0 + c] = s;
 	}
 	__syncthreads();
-	if (tid < 32 && n0 + tid < p.N) {
+	if (tid < T && n0 + tid < p.N) {
 		const int c = tid, col = n0 + tid;
 		float mx = -INFINITY;
-		for (int r = 0; r < p.M; r++) mx = fmaxf(mx, red[0][r * 33 + c]);
+		for (int r = 0; r < p.M; r++) mx = fmaxf(mx, red[r * RS + c]);
 		float sum = 0.f;
-		for (int r = 0; r < p.M; r++) { float e = expf(red[0][r * 33 + c] - mx); red[0][r * 33 + c] = e; sum += e; }
+		for (int r = 0; r < p.M; r++) { float e = expf(red[r * RS + c] - mx); red[r * RS + c] = e; sum += e; }
 		for (int r = 0; r < p.M; r++) {
-			float pr = red[0][r * 33 + c] / sum;
+			float pr = red[r * RS + c] / sum;
 			p.C[(size_t)r * p.ldc + col] = pr;
 			p.softmax_grad[(size_t)r * p.ldc + col] = (pr - p.softmax_y[(size_t)r * p.ldc + col]) * p.softmax_scale;
 		}
 	}
 }
 
-template <bool AKC, bool BKC, bool AVEC, bool BVEC>
+template <int T, bool AKC, bool BKC, bool AVEC, bool BVEC>
 __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 	__shared__ __attribute__((aligned(16))) WskShared sh;
-	wsk_body<AKC, BKC, AVEC, BVEC>(p, (int)blockIdx.x, (int)blockIdx.y, sh);
+	wsk_body<T, AKC, BKC, AVEC, BVEC>(p, (int)blockIdx.x, (int)blockIdx.y, sh);
 }
 
 // Two independent latency-bound products in ONE launch: workgroups [0, tiles_p) run product p, the rest product q.  In the
 // MNIST-NN backward pass dW_l = dZ_l . A_{l-1}^T (NT) and dZ_{l-1} = W_l^T . dZ_l (TN) both depend only on dZ_l: launched
 // together they overlap instead of queueing, which takes two ~5 us launches off the step's critical path.
+// Each product brings its own tile size (GemmArgs::wsk_tile).
 template <bool AKC1, bool BKC1, bool AKC2, bool BKC2>
 __global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, GemmArgs q, int tiles_p) {
 	__shared__ __attribute__((aligned(16))) WskShared sh;
-	if ((int)blockIdx.x < tiles_p) wsk_body<AKC1, BKC1, true, true>(p, (int)blockIdx.x, 0, sh);
-	else wsk_body<AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
+	if ((int)blockIdx.x < tiles_p) {
+		if (p.wsk_tile == 16) wsk_body<16, AKC1, BKC1, true, true>(p, (int)blockIdx.x, 0, sh);
+		else wsk_body<32, AKC1, BKC1, true, true>(p, (int)blockIdx.x, 0, sh);
+	} else {
+		if (q.wsk_tile == 16) wsk_body<16, AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
+		else wsk_body<32, AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
+	}
 }
 
 // Sums the split-K slabs in split order (deterministic) and applies the epilogue.
@@ -1283,6 +1312,7 @@ static const Config kConfigs[] = {
 	{128, 512, 16, 256, true, "glds128x512x16"},    // the same pipeline for products with 128 rows: four waves side by side, each 128x128
 	{128, 128, 16, 256, true, "glds128x128x16h"},   // the same pipeline on the 128x128 tile (whole tiles, plain epilogue)
 	{128, 256, 16, 256, true, "glds128x256x16h"},   // ... and on 128x256 (waves 2x2, each 64x128): +8 % on 128 x 1152 x 65536, behind elsewhere
+	{16, 16, 16, 256, false, "wsk16x16"},       // wave-split-K on 16x16 tiles (MFMA 16x16x4): forced form of what config 6 picks by itself for few tiles
 };
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -1351,13 +1381,15 @@ static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, 
 
 static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, bool bvec, dim3 grid, hipStream_t s) {
 	dim3 block(256);
-#define BLA_W(AK, BK_, AV, BV) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<AK, BK_, AV, BV>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
-#define BLA_WV(AK, BK_) do { if (avec && bvec) BLA_W(AK, BK_, true, true); if (avec) BLA_W(AK, BK_, true, false); if (bvec) BLA_W(AK, BK_, false, true); BLA_W(AK, BK_, false, false); } while (0)
+#define BLA_W(AK, BK_, AV, BV) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<32, AK, BK_, AV, BV>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
+#define BLA_W16(AK, BK_) do { hipLaunchKernelGGL((gemm_f32_wsk_kernel<16, AK, BK_, true, true>), grid, block, 0, s, a); return hipGetLastError(); } while (0)
+#define BLA_WV(AK, BK_) do { if (avec && bvec && a.wsk_tile == 16) BLA_W16(AK, BK_); if (avec && bvec) BLA_W(AK, BK_, true, true); if (avec) BLA_W(AK, BK_, true, false); if (bvec) BLA_W(AK, BK_, false, true); BLA_W(AK, BK_, false, false); } while (0)
 	if (akc && !bkc) BLA_WV(true, false);
 	if (akc && bkc) BLA_WV(true, true);
 	if (!akc && !bkc) BLA_WV(false, false);
 	BLA_WV(false, true);
 #undef BLA_WV
+#undef BLA_W16
 #undef BLA_W
 }
 
@@ -1510,22 +1542,42 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		}
 		else cfg = big ? 0 : 1;
 	}
-	if (cfg == 6) {   // wave-split-K kernel: one 32x32 tile per workgroup, K divided over its waves
+	const bool force_wsk16 = cfg == 16;
+	if (cfg == 16) cfg = 6;
+	if (cfg == 6) {   // wave-split-K kernel: one 32x32 (or 16x16) tile per workgroup, K divided over its waves
 		BLA_REQUIRE(k > 0, BLA_ERR_INVALID, "gemm config %d needs k > 0", cfg);
 		const int nw = 4;
-		a.tiles_m = (m + 31) / 32; a.tiles_n = (n + 31) / 32;
-		const long wtiles = (long)a.tiles_m * a.tiles_n;
+		// 16-byte loads per operand: along K for a K-contiguous operand, along the rows/columns for a row-contiguous one
+		const bool a_al = lda % 4 == 0 && (uintptr_t)A % 16 == 0, b_al = ldb % 4 == 0 && (uintptr_t)B % 16 == 0;
+		const bool avec = a_al && (akc ? (k % 4 == 0 && k >= 4) : (m % 4 == 0 && m >= 4));
+		const bool bvec = b_al && (bkc ? (k % 4 == 0 && k >= 4) : (n % 4 == 0 && n >= 4));
+		const long tiles32 = (long)((m + 31) / 32) * ((n + 31) / 32);
 		int ksplit = g_force_split > 0 ? g_force_split : 1;
 		// (automatic only for long contractions: at K <= 1280 the release/acquire hand-off (~2 us per doubling) costs what the
 		// shorter K loop saves -- measured 256x784x256: 11.0 / 10.8 / 11.2 us at 1 / 2 / 4 splits)
-		if (g_force_split <= 0 && wtiles < cus && k > 1280 && !a.row_sum_a && !a.softmax_grad) {   // idle CUs and a long K: cut K over workgroups too
-			long want = (cus + wtiles - 1) / wtiles, maxs = k / 128;
+		if (g_force_split <= 0 && tiles32 < cus && k > 1280 && !a.row_sum_a && !a.softmax_grad) {   // idle CUs and a long K: cut K over workgroups too
+			long want = (cus + tiles32 - 1) / tiles32, maxs = k / 128;
 			ksplit = (int)(want < maxs ? want : maxs);
 			if (ksplit > 8) ksplit = 8;
 			if (ksplit < 1) ksplit = 1;
 		}
-		if (a.row_sum_a || a.softmax_grad || wtiles > 16384) ksplit = 1;
-		a.k_per_split = (((k + ksplit - 1) / ksplit + nw - 1) / nw + 7) / 8 * 8;   // per-wave extent
+		if (a.row_sum_a || a.softmax_grad || tiles32 > 16384) ksplit = 1;
+		// Tile size: 16x16 tiles (four times the workgroups, half the operand bytes through each CU's memory queue) while the 32x32 tiling
+		// leaves CUs idle; BLA_WSK_TILE=16|32 forces it (experiments).
+		static const int forced_tile = [] { const char* e = getenv("BLA_WSK_TILE"); return e ? atoi(e) : 0; }();
+		static const long tile16_below = [] { const char* e = getenv("BLA_WSK_TILE16_BELOW"); return e ? atol(e) : 129L; }();
+		int tile = 32;
+		const bool can16 = avec && bvec && ksplit == 1 && (!a.softmax_grad || m <= 16);
+		if (force_wsk16) {
+			BLA_REQUIRE(can16, BLA_ERR_INVALID, "gemm config 16 (wsk16x16) needs 16-byte loads on both operands, no K split over workgroups and m <= 16 with the fused softmax");
+			tile = 16;
+		} else if (g_force_config == 6) tile = 32;
+		else if (can16 && (forced_tile == 16 || (forced_tile == 0 && tiles32 < tile16_below))) tile = 16;
+		a.wsk_tile = tile;
+		a.tiles_m = (m + tile - 1) / tile; a.tiles_n = (n + tile - 1) / tile;
+		const long wtiles = (long)a.tiles_m * a.tiles_n;
+		const int gk = tile == 16 ? 16 : 8;   // k per load group: the per-wave extent is a multiple of it
+		a.k_per_split = (((k + ksplit - 1) / ksplit + nw - 1) / nw + gk - 1) / gk * gk;
 		ksplit = (k + nw * a.k_per_split - 1) / (nw * a.k_per_split);
 		a.splits = ksplit; a.slab = nullptr; a.counters = ctx().tile_counters;
 #ifdef BLA_WSK_DIAG
@@ -1537,15 +1589,11 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (st) return st;
 			a.slab = (float*)ws;
 		}
-		// 16-byte loads per operand: along K for a K-contiguous operand, along the rows/columns for a row-contiguous one
-		const bool a_al = lda % 4 == 0 && (uintptr_t)A % 16 == 0, b_al = ldb % 4 == 0 && (uintptr_t)B % 16 == 0;
-		const bool avec = a_al && (akc ? (k % 4 == 0 && k >= 4) : (m % 4 == 0 && m >= 4));
-		const bool bvec = b_al && (bkc ? (k % 4 == 0 && k >= 4) : (n % 4 == 0 && n >= 4));
-		dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)ksplit);
+		dim3 grid((unsigned)wtiles, (unsigned)ksplit);
 		if (plan && ksplit == 1 && avec && bvec) { plan->a = a; plan->akc = akc; plan->bkc = bkc; plan->valid = true; return BLA_OK; }
 		hipError_t e = launch_wsk(a, akc, bkc, avec, bvec, grid, s);
 		if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk_kernel launch");
-		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s%s_ksplit%d", kConfigs[cfg].name, transa ? 't' : 'n', transb ? 't' : 'n',
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk%dx%d_%c%c_%s%s_ksplit%d", tile, tile, transa ? 't' : 'n', transb ? 't' : 'n',
 		         avec ? "v" : "s", bvec ? "v" : "s", ksplit);
 		return BLA_OK;
 	}
@@ -1674,8 +1722,8 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 		}
 #undef BLA_PAIR_CASE
 		e = hipGetLastError();
-		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk32x32_pair_%c%c+%c%c_%d+%d", pp.akc ? 'n' : 't', pp.bkc ? 't' : 'n', pq.akc ? 'n' : 't',
-		         pq.bkc ? 't' : 'n', tp, tq);
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk_pair_%c%c+%c%c_%dx%d+%dx%d", pp.akc ? 'n' : 't', pp.bkc ? 't' : 'n', pq.akc ? 'n' : 't',
+		         pq.bkc ? 't' : 'n', tp, pp.a.wsk_tile, tq, pq.a.wsk_tile);
 	} else {
 		if (pp.valid) e = launch_wsk(pp.a, pp.akc, pp.bkc, true, true, dim3((unsigned)tp, 1), s);
 		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);

@@ -156,7 +156,8 @@ BLA_API bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const
 
 /* Tuning/diagnostics: force a tile configuration (-1 = automatic) and split-K factor (0 = automatic).  Configurations
  * (csrc/bla_gemm.hip): 0-2 register-staged tiles (any shape); 3/4/5/7 direct-to-LDS 128x128x16, 64x64x16, 128x128x32, 128x64x16
- * (16-byte aligned operands, k a multiple of the slab depth); 6 wave-split-K 32x32 for latency-bound shapes; 8/9 256x128-class
+ * (16-byte aligned operands, k a multiple of the slab depth); 6 wave-split-K 32x32 for latency-bound shapes (16: its 16x16-tile form, which the automatic
+ * choice takes when the 32x32 tiling would leave CUs idle); 8/9 256x128-class
  * three-buffer tiles; 10 persistent 128x128; 11/12/13 the one-workgroup-per-CU half-slab kernels 256x256x16, 256x256x32, 128x512x16
  * and 14 their 128x128 form (whole tiles, plain alpha epilogue only).  A forced configuration that cannot take the call fails with
  * BLA_ERR_INVALID; the automatic choice never does. */

@@ -60,15 +60,18 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
     Configs 3-5 and 7-9 are the direct-to-LDS kernels: they need k % BK == 0 and extents % 4 == 0
     (8 and 9 are the three-buffer split-fragment pipeline; odd and even slab counts take different tails).
-    Config 6 is the wave-split-K kernel for latency-bound shapes (any shape, k > 0)."""
+    Config 6 is the wave-split-K kernel for latency-bound shapes (any shape, k > 0), 16 its 16x16-tile form (16-byte loads:
+    contiguous extents % 4 == 0; ragged tiles, K tails shorter than a load group and single-wave K included)."""
     dev.lib().bla_gemm_set_config(cfg, 0)
     shapes = [(1, 1, 1), (5, 3, 7), (64, 16, 64), (65, 17, 63), (130, 40, 129), (128, 128, 128), (257, 100, 31), (200, 260, 136)]
+    if cfg == 16:
+        shapes = [(4, 4, 4), (16, 16, 16), (20, 12, 36), (64, 64, 64), (68, 20, 60), (132, 100, 128), (128, 784, 48), (256, 256, 128), (260, 136, 36), (12, 1000, 52)]
     if 3 <= cfg <= 5 or cfg >= 7:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
                   (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128), (132, 112, 140), (128, 144, 128)]
@@ -201,13 +204,13 @@ def test_large_square_sampled_rows(dev, ora, n):
     assert np.array_equal(c2, 2 * c)                                         # power-of-two scaling is exact
 
 
-@pytest.mark.parametrize("cfg", [-1, 1, 4, 6])
+@pytest.mark.parametrize("cfg", [-1, 1, 4, 6, 16])
 def test_fused_row_sum_of_a(dev, ora, cfg):
     """row_sum_a[r] = sum_k A[r][k] rides along the product (bias gradient = true row sums of dZ, the intent of
     matrix_col_sum, model/mnist_nn.c:271): fused in the wave-split-K kernels, a separate pass behind the tiled ones."""
     dev.lib().bla_gemm_set_config(cfg, 0)
     try:
-        for (m, k, n) in [(10, 256, 128), (128, 256, 256), (70, 96, 40)]:
+        for (m, k, n) in [(10, 256, 128), (128, 256, 256), (70, 96, 40)] if cfg != 16 else [(10, 256, 128), (128, 256, 256), (72, 96, 40), (256, 256, 784)]:
             a = uniform(31, (m, k), dtype=np.float32); b = uniform(32, (n, k), dtype=np.float32)
             rs = dev.empty((m,)).fill_bytes(0xFF); c = dev.empty((m, n))
             dev.gemm(dev.to_device(a), dev.to_device(b), c, transb=True, row_sum_a=rs)
@@ -218,9 +221,18 @@ def test_fused_row_sum_of_a(dev, ora, cfg):
         dev.lib().bla_gemm_set_config(-1, 0)
 
 
-def test_fused_softmax_tail(dev, ora):
+@pytest.mark.parametrize("cfg", [6, 16])
+def test_fused_softmax_tail(dev, ora, cfg):
     """Output layer in one launch: Z = W A + b (kept), P = softmax per column, grad = (P - Y) * scale
-    (model/mnist_nn.c:231-234,260-268)."""
+    (model/mnist_nn.c:231-234,260-268); on 32x32 tiles (m <= 32) and on 16x16 tiles (m <= 16)."""
+    dev.lib().bla_gemm_set_config(cfg, 0)
+    try:
+        _fused_softmax_tail(dev, ora)
+    finally:
+        dev.lib().bla_gemm_set_config(-1, 0)
+
+
+def _fused_softmax_tail(dev, ora):
     m, k, n = 10, 128, 300
     w = uniform(41, (m, k), dtype=np.float32); x = uniform(42, (k, n), -2, 2, np.float32); b = uniform(43, (m, 1), dtype=np.float32)
     y = np.zeros((m, n), np.float32); y[np.arange(n) % m, np.arange(n)] = 1
@@ -383,7 +395,7 @@ def test_automatic_dispatch_fuzz(dev):
         assert np.all(np.abs(got[:, :n] - ref) <= 1e-5 * bound + 1e-6), (case, m, n, k, ta, tb, mode, name)
         if pad_c:
             assert np.array_equal(got[:, n:], Cbuf[:, n:]), ("wrote outside the view", case, name)
-    assert "wsk32x32" in seen and len(seen) >= 4, seen
+    assert ("wsk32x32" in seen or "wsk16x16" in seen) and len(seen) >= 4, seen
     # the 256x256 kernel needs a chip-filling product on whole tiles with a plain epilogue: all four layouts, padded pitches, alpha
     for ta, tb in [(0, 0), (0, 1), (1, 0), (1, 1)]:
         m, n, k = 4096, 4096, 80
