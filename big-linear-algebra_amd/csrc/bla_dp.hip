@@ -240,6 +240,7 @@ struct bla_dp {
 	void* peer_flags[kMaxWorld];
 	bool peer_ipc[kMaxWorld];    // opened through hipIpcOpenMemHandle (to be closed)
 	bool connected;
+	unsigned long long steps;    // data-parallel steps issued through this object: the trainers take their bucket parity from here
 };
 
 // What one rank tells the others (BLA_DP_HANDLE_BYTES opaque bytes): IPC handles for other processes, plain pointers for ranks that
@@ -257,7 +258,11 @@ static unsigned long long process_nonce() {
 	return n;
 }
 static std::atomic<unsigned long long> g_next_dp_id{1};
-namespace bla { unsigned long long dp_identity(const bla_dp* dp) { return dp ? dp->id : 0; } }
+namespace bla {
+unsigned long long dp_identity(const bla_dp* dp) { return dp ? dp->id : 0; }
+int dp_parity(const bla_dp* dp) { return (int)(dp->steps & 1); }
+void dp_advance(bla_dp* dp) { dp->steps++; }
+}
 
 extern "C" {
 
@@ -292,6 +297,7 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	for (int r = 0; r < kMaxWorld; r++) { dp->peer[r] = nullptr; dp->peer_flags[r] = nullptr; dp->peer_ipc[r] = false; }
 	dp->peer[rank] = dp->base; dp->peer_flags[rank] = dp->flags;
 	dp->connected = world == 1;
+	dp->steps = 0;
 	*out = dp;
 	return BLA_OK;
 }

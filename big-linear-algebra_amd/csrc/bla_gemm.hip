@@ -47,6 +47,7 @@ struct GemmArgs {
 	float* row_sum_a;              // fused bias gradient: row_sum_a[r] = sum_k op(A)[r][k]   (wsk kernels, A K-contiguous)
 	float rs_alpha, rs_beta;       // ... stored as rs_beta * old + rs_alpha * sum (1, 0 = plain)
 	const float* softmax_y; float softmax_scale; float* softmax_grad;   // fused column softmax + (p - y)*scale (wsk kernels, M <= 32)
+	double* sm_loss; unsigned* sm_correct;   // optional per-column accumulators of the loss / accuracy bookkeeping (model/mnist_nn.c:237-257)
 	// implicit-GEMM convolution over a batch of images (gather variants of the direct-to-LDS kernel only): the B operand is
 	// never stored, element (k, n) is img[g_off(k) + g_off(n)] when (y(k) + y(n), x(k) + x(n)) lies inside the H x W image, else 0.
 	//   mode 1 (forward / data gradient): n = (image, output pixel), k = tap (c, p, q);  C is written as [image][M][HWo]
@@ -1254,10 +1255,24 @@ __device__ __forceinline__ void wsk_body(GemmArgs p, const int bx, const int by,
 		for (int r = 0; r < p.M; r++) mx = fmaxf(mx, red[r * RS + c]);
 		float sum = 0.f;
 		for (int r = 0; r < p.M; r++) { float e = expf(red[r * RS + c] - mx); red[r * RS + c] = e; sum += e; }
+		// bookkeeping of model/mnist_nn.c:237-257 for this column: prediction = first row whose probability exceeds every earlier one
+		// (`> max_confidence` from 0), correct when the one-hot label has a 1 there; loss = -sum_r y * log(p + LOSS_EPSILON) in double.  Rows
+		// with y == 0 contribute an exact -0.0 there (the logarithm is finite) and are skipped.  The reference walks the flat 10 x B arrays
+		// in chunks of 10 (:252-254): over a whole batch that is the same set of terms, so the batch totals agree.
+		int pred = 0; float best = 0.f; double loss = 0.0;
 		for (int r = 0; r < p.M; r++) {
 			float pr = red[r * RS + c] / sum;
+			const float yv = p.softmax_y[(size_t)r * p.ldc + col];
 			p.C[(size_t)r * p.ldc + col] = pr;
-			p.softmax_grad[(size_t)r * p.ldc + col] = (pr - p.softmax_y[(size_t)r * p.ldc + col]) * p.softmax_scale;
+			p.softmax_grad[(size_t)r * p.ldc + col] = (pr - yv) * p.softmax_scale;
+			if (p.sm_loss) {
+				if (pr > best) { best = pr; pred = r; }
+				if (yv != 0.f) loss += -1.0 * ((double)yv * log((double)pr + 1e-15));
+			}
+		}
+		if (p.sm_loss) {   // one thread owns a column's slots: plain read-modify-write, deterministic
+			p.sm_loss[col] += loss;
+			p.sm_correct[col] += p.softmax_y[(size_t)pred * p.ldc + col] == 1.f ? 1u : 0u;
 		}
 	}
 }
@@ -1497,6 +1512,9 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		a.rc_global = (transa ? pow2_small(lda) : true) && (!transb ? pow2_small(ldb) : true);
 	}
 	a.softmax_y = ep ? ep->softmax_y : nullptr; a.softmax_scale = ep ? ep->softmax_scale : 0.f; a.softmax_grad = ep ? ep->softmax_grad : nullptr;
+	a.sm_loss = ep ? ep->softmax_loss_acc : nullptr; a.sm_correct = ep ? ep->softmax_correct_acc : nullptr;
+	BLA_REQUIRE((a.sm_loss == nullptr) == (a.sm_correct == nullptr) && (!a.sm_loss || a.softmax_grad), BLA_ERR_INVALID,
+	            "softmax_loss_acc and softmax_correct_acc go together and need the fused softmax tail");
 	BLA_REQUIRE(!a.row_sum_a || !transa, BLA_ERR_INVALID, "row_sum_a needs a non-transposed A");
 	BLA_REQUIRE((a.softmax_y == nullptr) == (a.softmax_grad == nullptr), BLA_ERR_INVALID, "softmax_y and softmax_grad go together");
 	BLA_REQUIRE(!a.softmax_grad || (m <= 32 && a.beta == 0.f && !a.relu_mask && a.act == BLA_ACT_NONE && !a.bias_col && k > 0), BLA_ERR_INVALID,

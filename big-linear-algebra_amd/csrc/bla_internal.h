@@ -55,6 +55,10 @@ bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_de
 
 // bla_dp.hip: identity of an exchange object that survives address reuse (a destroyed and re-created object never has the same id)
 unsigned long long dp_identity(const bla_dp* dp);
+// gradient-bucket parity of the next data-parallel step through this exchange object / count one step (several trainers -- the full-batch
+// one and the one for an epoch's last, shorter batch -- may share an exchange object: the parity must alternate over ALL their steps)
+int dp_parity(const bla_dp* dp);
+void dp_advance(bla_dp* dp);
 
 #define BLA_HIP(call)                                               \
 	do {                                                            \

@@ -35,7 +35,9 @@ struct bla_mnist_nn {
 	std::vector<void*> owned;
 	hipGraph_t graph; hipGraphExec_t graph_exec; bool graph_ready; int graph_colsum; float graph_lr;
 	// data-parallel step: one graph per gradient-bucket parity (the exchange object double-buffers the bucket)
-	hipGraph_t dp_graph[2]; hipGraphExec_t dp_exec[2]; bool dp_ready[2]; unsigned long long dp_bound_id; float dp_lr; unsigned long long dp_steps;
+	hipGraph_t dp_graph[2]; hipGraphExec_t dp_exec[2]; bool dp_ready[2]; unsigned long long dp_bound_id; float dp_lr;
+	// loss / accuracy bookkeeping (model/mnist_nn.c:237-257): per-column device accumulators, fed by the output layer's launch when enabled
+	double* m_loss; unsigned* m_correct; bool metrics_on;
 };
 
 using namespace bla;
@@ -68,7 +70,8 @@ bla_status bla_mnist_nn_create(bla_mnist_nn** out, const int* sizes, int batch) 
 	nn->count = o;
 	nn->own_buckets = true;
 	nn->graph_ready = false;
-	nn->dp_ready[0] = nn->dp_ready[1] = false; nn->dp_bound_id = 0; nn->dp_lr = 0.f; nn->dp_steps = 0;
+	nn->dp_ready[0] = nn->dp_ready[1] = false; nn->dp_bound_id = 0; nn->dp_lr = 0.f;
+	nn->m_loss = nullptr; nn->m_correct = nullptr; nn->metrics_on = false;
 	const size_t B = batch;
 	st = dev_alloc(nn, &nn->params, o); if (st) return st;
 	st = dev_alloc(nn, &nn->grads, o); if (st) return st;
@@ -153,27 +156,14 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 	return forward_backward_into(nn, stream, d_x_raw, d_y, colsum_mode, nn->grads);
 }
 
-static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads) {
-	bla_status st = require_ready();
-	if (st) return st;
-	if (!d_x_raw) d_x_raw = nn->x_raw;
-	if (!d_y) d_y = nn->y;
+/* Z1 = W1 (x / 255) + b1, A1 = relu; Z2, A2 likewise; Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) / n0; with the
+ * loss / accuracy accumulators fed from the output layer's launch when enabled (model/mnist_nn.c:218-268). */
+static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x_raw, const float* d_y) {
 	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
-	if (colsum_mode == BLA_COLSUM_AS_WRITTEN && (n1 > B || n2 > B || n3 > B)) {
-		set_error("matrix_col_sum as written is out of bounds for layer sizes %d/%d/%d at batch %d (rows > cols, SURVEY Q2)", n1, n2, n3, B);
-		return BLA_ERR_UNDEFINED;
-	}
 	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
 	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
-	float *dW1 = grads + nn->off[0], *db1 = grads + nn->off[1], *dW2 = grads + nn->off[2], *db2 = grads + nn->off[3];
-	float *dW3 = grads + nn->off[4], *db3 = grads + nn->off[5];
-	hipStream_t s = pick_stream(stream);
-
-	// The input scale of :218 (x *= 1/255.0F, a float expression) is folded into the two products that read X:
-	// W1.(s x) = s (W1.x) and dZ1.(s x)^T = s (dZ1.x^T) -- no pass over the 784 x B input at all.
 	const float xs = 1 / 255.0F;
-	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
-
+	bla_status st;
 	bla_gemm_epilogue ep = {};
 	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
 	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, d_x_raw, B, nn->a1, B, &ep); if (st) return st;         // :221-224
@@ -185,11 +175,36 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	const float gscale = (float)(1 / (double)n0);
 	if (n3 <= 32) {
 		ep.softmax_y = d_y; ep.softmax_scale = gscale; ep.softmax_grad = nn->dz3;
+		if (nn->metrics_on) { ep.softmax_loss_acc = nn->m_loss; ep.softmax_correct_acc = nn->m_correct; }
 		st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
 	} else {
 		st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
 		st = bla_softmax_cols_grad_f32(s, nn->a3, n3, B, d_y, gscale, nn->dz3); if (st) return st;
 	}
+	return BLA_OK;
+}
+
+static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads) {
+	bla_status st = require_ready();
+	if (st) return st;
+	if (!d_x_raw) d_x_raw = nn->x_raw;
+	if (!d_y) d_y = nn->y;
+	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
+	if (colsum_mode == BLA_COLSUM_AS_WRITTEN && (n1 > B || n2 > B || n3 > B)) {
+		set_error("matrix_col_sum as written is out of bounds for layer sizes %d/%d/%d at batch %d (rows > cols, SURVEY Q2)", n1, n2, n3, B);
+		return BLA_ERR_UNDEFINED;
+	}
+	float *W2 = nn->params + nn->off[2], *W3 = nn->params + nn->off[4];
+	float *dW1 = grads + nn->off[0], *db1 = grads + nn->off[1], *dW2 = grads + nn->off[2], *db2 = grads + nn->off[3];
+	float *dW3 = grads + nn->off[4], *db3 = grads + nn->off[5];
+	hipStream_t s = pick_stream(stream);
+
+	// The input scale of :218 (x *= 1/255.0F, a float expression) is folded into the two products that read X:
+	// W1.(s x) = s (W1.x) and dZ1.(s x)^T = s (dZ1.x^T) -- no pass over the 784 x B input at all.
+	const float xs = 1 / 255.0F;
+	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
+
+	st = forward_pass(nn, s, d_x_raw, d_y); if (st) return st;
 
 	// (Measured and not kept: running the layer-3 / layer-2 weight-gradient products on a side stream -- parallel branches of
 	// the captured graph -- to take two launches off the critical path.  The cross-queue dependencies cost more than the
@@ -259,15 +274,8 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
 	const float* x = d_x_raw ? d_x_raw : nn->x_raw; const float* y = d_y ? d_y : nn->y;
 	const float xs = 1 / 255.0F;
-	bla_status st;
-	bla_gemm_epilogue ep = {};
-	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
-	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, x, B, nn->a1, B, &ep); if (st) return st;
-	ep.alpha = 1.f; ep.bias_row = b2; ep.pre_act = nn->z2;
-	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;
-	ep.bias_row = b3; ep.pre_act = nn->z3; ep.act = BLA_ACT_NONE;
-	ep.softmax_y = y; ep.softmax_scale = (float)(1 / (double)n0); ep.softmax_grad = nn->dz3;
-	st = bla_gemm_f32(s, 0, 0, n3, B, n2, W3, n2, nn->a2, B, nn->a3, B, &ep); if (st) return st;
+	bla_status st = forward_pass(nn, s, x, y);
+	if (st) return st;
 	bla_gemm_epilogue em2 = {};
 	em2.alpha = 1.f; em2.relu_mask = nn->z2; em2.ld_mask = B;
 	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st;        // dZ2: last reader of W3
@@ -287,6 +295,92 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 		bla_gemm_desc p1 = {0, 1, n1, n0, B, nn->dz1, B, x, B, W1, n0, &u1};
 		st = bla_gemm_pair_f32(s, &p2, &p1); if (st) return st;
 	}
+	return BLA_OK;
+}
+
+/* model/mnist_nn.c:221-234 alone (and the whole of run(), :447-463). */
+bla_status bla_mnist_nn_forward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	return forward_pass(nn, pick_stream(stream), d_x_raw ? d_x_raw : nn->x_raw, d_y ? d_y : nn->y);
+}
+
+static void drop_graphs(bla_mnist_nn* nn) {
+	if (nn->graph_ready) { (void)hipGraphExecDestroy(nn->graph_exec); (void)hipGraphDestroy(nn->graph); nn->graph_ready = false; }
+	for (int i = 0; i < 2; i++)
+		if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
+}
+
+/* Loss / accuracy bookkeeping of model/mnist_nn.c:237-257 (and run(), :476-490) inside the output layer's launch: one double and one
+ * counter per batch column, each owned by one thread of that launch.  Recorded graphs bake the pointers in, so toggling drops them. */
+bla_status bla_mnist_nn_metrics_enable(bla_mnist_nn* nn, int on) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
+	BLA_REQUIRE(!on || nn->n[3] <= 32, BLA_ERR_INVALID, "device-side loss / accuracy needs an output layer of at most 32 classes (fused softmax tail)");
+	if ((on != 0) == nn->metrics_on) return BLA_OK;
+	BLA_HIP(hipDeviceSynchronize());
+	drop_graphs(nn);
+	if (on && !nn->m_loss) {
+		float* p = nullptr;
+		st = dev_alloc(nn, &p, 2 * (size_t)nn->batch); if (st) return st;     // doubles
+		nn->m_loss = (double*)p;
+		st = dev_alloc(nn, &p, (size_t)nn->batch); if (st) return st;
+		nn->m_correct = (unsigned*)p;
+	}
+	if (on) {
+		BLA_HIP(hipMemsetAsync(nn->m_loss, 0, nn->batch * sizeof(double), ctx().stream));
+		BLA_HIP(hipMemsetAsync(nn->m_correct, 0, nn->batch * sizeof(unsigned), ctx().stream));
+		BLA_HIP(hipStreamSynchronize(ctx().stream));
+	}
+	nn->metrics_on = on != 0;
+	return BLA_OK;
+}
+
+bla_status bla_mnist_nn_metrics_read(bla_mnist_nn* nn, double* loss_sum, long long* num_correct, int reset) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn && loss_sum && num_correct, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(nn->metrics_on, BLA_ERR_INVALID, "bla_mnist_nn_metrics_enable has not run");
+	BLA_HIP(hipDeviceSynchronize());
+	std::vector<double> l(nn->batch); std::vector<unsigned> c(nn->batch);
+	BLA_HIP(hipMemcpy(l.data(), nn->m_loss, nn->batch * sizeof(double), hipMemcpyDeviceToHost));
+	BLA_HIP(hipMemcpy(c.data(), nn->m_correct, nn->batch * sizeof(unsigned), hipMemcpyDeviceToHost));
+	double ls = 0; long long cs = 0;
+	for (int i = 0; i < nn->batch; i++) { ls += l[i]; cs += c[i]; }   // column order
+	*loss_sum = ls; *num_correct = cs;
+	if (reset) {
+		BLA_HIP(hipMemset(nn->m_loss, 0, nn->batch * sizeof(double)));
+		BLA_HIP(hipMemset(nn->m_correct, 0, nn->batch * sizeof(unsigned)));
+		BLA_HIP(hipDeviceSynchronize());
+	}
+	return BLA_OK;
+}
+
+/* The batch construction loop of model/mnist_nn.c:204-217 on the device: column k of the input is example idx[k] of the resident,
+ * feature-major dataset (lib/mnist_csv2.c's layout), column k of the label matrix its one-hot label. */
+namespace {
+__global__ void __launch_bounds__(256) mnist_gather_kernel(const float* __restrict__ X, const float* __restrict__ labels, int num_examples,
+                                                           const int* __restrict__ idx, float* __restrict__ x_raw, float* __restrict__ y, int n0, int n3, int B) {
+	const int total = (n0 + n3) * B;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		const int row = e / B, k = e - row * B;
+		const int ex = idx[k];
+		if (row < n0) x_raw[e] = X[(size_t)row * num_examples + ex];                    // input_data[k + B * p] = ex.X[p * num_examples], :208-210
+		else y[e - n0 * B] = (int)labels[ex] == row - n0 ? 1.f : 0.f;                    // expectations[k + expectation * B] = 1, :212-216
+	}
+}
+}  // namespace
+
+bla_status bla_mnist_nn_gather_batch(bla_mnist_nn* nn, void* stream, const float* d_X, const float* d_labels, int num_examples, const int* d_indices) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(nn && d_X && d_labels && d_indices && num_examples > 0, BLA_ERR_INVALID, "null / empty argument");
+	const int total = (nn->n[0] + nn->n[3]) * nn->batch;
+	hipLaunchKernelGGL(mnist_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, pick_stream(stream), d_X, d_labels, num_examples, d_indices,
+	                   nn->x_raw, nn->y, nn->n[0], nn->n[3], nn->batch);
+	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
 
@@ -346,7 +440,7 @@ bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, floa
 			if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
 		nn->dp_bound_id = dp_identity(dp); nn->dp_lr = lr;
 	}
-	const int par = (int)(nn->dp_steps & 1);
+	const int par = dp_parity(dp);
 	if (!nn->dp_ready[par]) {
 		BLA_HIP(hipStreamSynchronize(s));
 		BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -359,7 +453,7 @@ bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, floa
 		nn->dp_ready[par] = true;
 	}
 	BLA_HIP(hipGraphLaunch(nn->dp_exec[par], s));
-	nn->dp_steps++;
+	dp_advance(dp);
 	return BLA_OK;
 }
 
@@ -372,12 +466,12 @@ bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* strea
 	BLA_REQUIRE(colsum_mode == BLA_COLSUM_INTENDED, BLA_ERR_INVALID, "a sharded batch needs BLA_COLSUM_INTENDED (true row sums)");
 	BLA_REQUIRE(bla_dp_count(dp) == nn->count, BLA_ERR_SHAPE, "exchange bucket holds %zu floats, the trainer has %zu parameters", bla_dp_count(dp), nn->count);
 	hipStream_t s = pick_stream(stream);
-	const int par = (int)(nn->dp_steps & 1);
+	const int par = dp_parity(dp);
 	st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par));
 	if (st) return st;
 	st = bla_dp_allreduce_f32(dp, s, par, nullptr, nn->params, lr);
 	if (st) return st;
-	nn->dp_steps++;
+	dp_advance(dp);
 	return BLA_OK;
 }
 

@@ -49,6 +49,7 @@ MnistExample get_random_data_take(MnistCSV* store) {     /* reference lib/mnist_
 	int at = 0;
 	for (; at < store->num_examples && skip > 0; at++)
 		if (!store->sampled[at]) skip--;
+	if (at >= store->num_examples) at = store->num_examples - 1;   /* the reference marks one past its array here (only when rand() rounds to RAND_MAX in float) */
 	store->sampled[at] = 1;
 	store->num_sampled++;
 	MnistExample out = {store->X + at, store->y[at], store->num_examples};

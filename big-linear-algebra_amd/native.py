@@ -22,7 +22,8 @@ class Epilogue(C.Structure):
     _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("bias_row", C.c_void_p), ("bias_col", C.c_void_p),
                 ("pre_act", C.c_void_p), ("ld_pre", C.c_int), ("act", C.c_int), ("relu_mask", C.c_void_p),
                 ("ld_mask", C.c_int), ("row_sum_a", C.c_void_p), ("softmax_y", C.c_void_p), ("softmax_scale", C.c_float),
-                ("softmax_grad", C.c_void_p), ("row_sum_alpha", C.c_float), ("row_sum_beta", C.c_float)]
+                ("softmax_grad", C.c_void_p), ("row_sum_alpha", C.c_float), ("row_sum_beta", C.c_float),
+                ("softmax_loss_acc", C.c_void_p), ("softmax_correct_acc", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -92,6 +93,8 @@ SIGNATURES = {
     "bla_mnist_nn_forward_backward": (_I, [_VP, _VP, _VP, _VP, _I]), "bla_mnist_nn_apply": (_I, [_VP, _VP, _F]),
     "bla_mnist_nn_train_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]), "bla_mnist_nn_graph_step": (_I, [_VP, _VP, _F, _I, _I]),
     "bla_mnist_nn_fused_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]),
+    "bla_mnist_nn_gather_batch": (_I, [_VP, _VP, _VP, _VP, _I, _VP]), "bla_mnist_nn_forward": (_I, [_VP, _VP, _VP, _VP]),
+    "bla_mnist_nn_metrics_enable": (_I, [_VP, _I]), "bla_mnist_nn_metrics_read": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _I]),
     "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]),
     "bla_diag_mfma_rate": (_I, [_VP, _I, _I, _I, _VP]),
     "bla_graph_begin": (_I, [_VP]), "bla_graph_end": (_I, [_VP, C.POINTER(_VP)]), "bla_graph_launch": (_I, [_VP, _VP]),

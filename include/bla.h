@@ -137,6 +137,12 @@ typedef struct bla_gemm_epilogue {
 	/* row_sum_a[r] = row_sum_beta * row_sum_a[r] + row_sum_alpha * sum_k A[r][k]; both 0 (a zero-initialised struct) = plain store of the
 	 * sum.  With alpha = learn rate, beta = 1 the bias update b += lr * db rides along the weight-gradient product (latency-bound kernels only). */
 	float row_sum_alpha, row_sum_beta;
+	/* with the fused softmax tail: per-COLUMN accumulators (length n) of the reference's loss / accuracy bookkeeping, model/mnist_nn.c:237-257:
+	 *   softmax_loss_acc[c]    += -sum_r y[r][c] * log(p[r][c] + 1e-15)            (double, LOSS_EPSILON of :15)
+	 *   softmax_correct_acc[c] += y[pred][c] == 1, pred = first row with the largest probability (> 0)
+	 * both NULL = off.  Summed over the columns they are the batch totals the reference adds into its epoch averages. */
+	double* softmax_loss_acc;
+	unsigned* softmax_correct_acc;
 } bla_gemm_epilogue;
 
 BLA_API bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int k,
@@ -302,6 +308,20 @@ BLA_API bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which /* 0..8: 
 BLA_API bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode);
 BLA_API bla_status bla_mnist_nn_apply(bla_mnist_nn* nn, void* stream, float lr /* reference: (float)-0.02 */);
 BLA_API bla_status bla_mnist_nn_train_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode);
+/* ---- the rest of the reference's training loop, device-resident (examples/mnist_nn_gpu.c drives these from C) ----
+ * Batch construction, model/mnist_nn.c:204-217: with the whole dataset resident in HBM in the reference's feature-major layout
+ * (lib/mnist_csv2.c: X[pixel * num_examples + example], labels y[example]) the host only sends the example indices its sampler drew;
+ * x_raw[p][k] = X[p * num_examples + idx[k]], one-hot[label][k] = 1 land in the trainer's resident input / label buffers. */
+BLA_API bla_status bla_mnist_nn_gather_batch(bla_mnist_nn* nn, void* stream, const float* d_X, const float* d_labels, int num_examples,
+                                             const int* d_indices);
+/* Forward pass only (model/mnist_nn.c:221-234; the whole of run(), :447-463): fills z1..a3 (and dz3, which run() ignores). */
+BLA_API bla_status bla_mnist_nn_forward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y);
+/* Loss / accuracy bookkeeping (model/mnist_nn.c:237-257, run(): :476-490) inside the output layer's launch: once enabled every forward
+ * pass adds its batch's cross-entropy (double) and its number of correct predictions to device-side accumulators -- no extra launch, no
+ * host round trip per batch.  read: synchronises, returns the totals since the last reset (summed over the batch columns in order). */
+BLA_API bla_status bla_mnist_nn_metrics_enable(bla_mnist_nn* nn, int on);
+BLA_API bla_status bla_mnist_nn_metrics_read(bla_mnist_nn* nn, double* loss_sum, long long* num_correct, int reset);
+
 /* One step with the update folded into the weight-gradient products (see graph_step below), issued directly on the stream: six launches
  * from one host call, no gradient bucket.  Falls back to bla_mnist_nn_train_step where the fused form does not apply. */
 BLA_API bla_status bla_mnist_nn_fused_step(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, float lr, int colsum_mode);

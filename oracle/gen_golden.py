@@ -264,6 +264,28 @@ def ref_mnist_step(params, x_raw, y, intended_colsum):
     return new, dict(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, a3=a3), grads
 
 
+def ref_mnist_metrics(a3, y):
+    """The bookkeeping of model/mnist_nn.c:237-257 for one batch: num_correct by the loop of :240-250, batch_loss by the reference's own
+    cross_entropy_loss (:83-91, from oracle/_ref/libref_mnist.so) on the flat chunks [10k, 10k+10) of both matrices exactly as :252-254
+    takes them, added in k order."""
+    M = C.CDLL(os.path.join(HERE, "_ref", "libref_mnist.so"))
+    M.cross_entropy_loss.restype = C.c_double
+    M.cross_entropy_loss.argtypes = [PD, PD, C.c_int]
+    a3 = np.ascontiguousarray(a3, np.float64); y = np.ascontiguousarray(y, np.float64)
+    n3, B = a3.shape
+    correct, loss = 0, 0.0
+    for k in range(B):
+        pred, best = 0, 0.0
+        for p in range(n3):
+            if a3[p, k] > best:
+                best, pred = a3[p, k], p
+        if y.ravel()[k + pred * B] == 1:
+            correct += 1
+        off = k * n3 * 8
+        loss += M.cross_entropy_loss(C.cast(a3.ctypes.data + off, PD), C.cast(y.ctypes.data + off, PD), n3)
+    return loss, correct
+
+
 def load_mnist_params():
     shapes = [(256, 784), (256, 1), (128, 256), (128, 1), (10, 128), (10, 1)]
     files = ["weights_1", "biases_1", "weights_2", "biases_2", "weights_3", "biases_3"]
@@ -287,6 +309,8 @@ def gen_mnist():
             put(d, f"{tag}_{n}", v, 4096)
         for n, v in acts.items():
             put(d, f"{tag}_{n}", v, 4096)
+        loss, correct = ref_mnist_metrics(acts["a3"], y)
+        d[f"{tag}_batch_loss"] = np.array(loss); d[f"{tag}_num_correct"] = np.array(correct, np.int64)
     # tiny architecture stored in full: 12 -> 8 -> 6 -> 4, B = 16 (all col_sum windows in bounds)
     sizes = (12, 8, 6, 4); B = 16
     tp = [uniform(3200, (8, 12)), uniform(3201, (8, 1)), uniform(3202, (6, 8)), uniform(3203, (6, 1)),
@@ -301,6 +325,8 @@ def gen_mnist():
             d[f"{tag}_{n}"] = v
         for n, v in acts.items():
             d[f"{tag}_{n}"] = v
+        loss, correct = ref_mnist_metrics(acts["a3"], y)
+        d[f"{tag}_batch_loss"] = np.array(loss); d[f"{tag}_num_correct"] = np.array(correct, np.int64)
     np.savez_compressed(os.path.join(GOLD, "mnist_step.npz"), **d)
 
 

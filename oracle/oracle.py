@@ -360,6 +360,27 @@ def print_matrix_text(m):
     return "".join(out).encode()
 
 
+def mnist_metrics(a3, y):
+    """model/mnist_nn.c:237-257 for one batch: (batch_loss, num_correct).  Prediction = first row whose probability exceeds every earlier
+    one, starting from 0 (:241-247); correct when the one-hot matrix has a 1 there (:248); loss = cross_entropy_loss (:83-91, LOSS_EPSILON
+    1e-15) over the flat chunks [10k, 10k+10) of both matrices as :252-254 takes them, added in k order."""
+    a3 = np.ascontiguousarray(a3, np.float64); y = np.ascontiguousarray(y, np.float64)
+    n3, B = a3.shape
+    fa, fy = a3.ravel(), y.ravel()
+    correct, loss = 0, 0.0
+    for k in range(B):
+        pred, best = 0, 0.0
+        for p in range(n3):
+            if a3[p, k] > best:
+                best, pred = a3[p, k], p
+        correct += int(fy[k + pred * B] == 1)
+        chunk = 0.0
+        for i in range(k * n3, k * n3 + n3):
+            chunk += -1 * (fy[i] * np.log(fa[i] + 1e-15))
+        loss += chunk
+    return loss, correct
+
+
 # ---- error-bound helpers ------------------------------------------------------
 def matmul_f32_acc64(a, b):
     a, b = _c(a, np.float32), _c(b, np.float32)
