@@ -201,13 +201,13 @@ static void train(int num_epochs, int batch, int colsum_mode) {
 		if (gpus > 1) CHECK(bla_context_create(&rep[r].ctx, share ? 0 : r));
 		use(&rep[r]);
 		CHECK(bla_mnist_nn_create(&rep[r].nn, kSizes, per));
-		CHECK(bla_mnist_nn_set_params(rep[r].nn, flat));
 		CHECK(bla_mnist_nn_metrics_enable(rep[r].nn, 1));
-		if (last != batch) {
+		if (last != batch) {      /* adopting a bucket copies the adopter's current parameters into it: load the weights afterwards */
 			CHECK(bla_mnist_nn_create(&rep[r].tail, kSizes, last / gpus));
 			CHECK(bla_mnist_nn_use_buckets(rep[r].tail, bla_mnist_nn_params(rep[r].nn), bla_mnist_nn_grads(rep[r].nn)));
 			CHECK(bla_mnist_nn_metrics_enable(rep[r].tail, 1));
 		}
+		CHECK(bla_mnist_nn_set_params(rep[r].nn, flat));
 		upload_dataset(&rep[r], &store);
 		if (gpus > 1) {
 			CHECK(bla_dp_create(&rep[r].dp, r, gpus, bla_mnist_nn_param_count(rep[r].nn)));

@@ -128,20 +128,9 @@ def test_train_and_run_against_the_oracle(prog, ora, tmp_path, gpus):
     r = run(prog, ["train", str(epochs), str(batch)], str(cwd), env)
     got_lines = [l for l in r.stdout.splitlines() if l.startswith("Epoch")]
     got = read_weights(str(cwd / "data" / "mnist_nn"))
-    # the program draws: srand(42), then per epoch `rows` picks after a sampler reset
-    order = []
-    import ctypes
-    libc = ctypes.CDLL(None)
-    path = str(cwd / "data" / "mnist" / "mnist_train.csv")
-    # `order ... walk` draws 2 * rows picks in one go; the program resets the sampler between epochs, which for a full pass is what the
-    # walk does by itself once everything was taken -- only when every pick of the first pass was distinct; so draw per epoch instead:
-    # epoch 1 = first `rows` picks after srand(42); epoch 2 continues the rand() stream on a cleared store.
-    both = sampler_order(prog, path, rows, str(cwd))
-    # second epoch: rand() continues; reproduce by asking for 2 * rows draws from a store that starts over after `rows` draws (the
-    # library resets itself when num_sampled == num_examples, exactly the state the program's memset creates)
-    both2 = sampler_order(prog, path, 2 * rows, str(cwd))
-    assert both2[:rows] == both
-    order = both2
+    # The program draws `rows` picks per epoch after srand(42), resetting the sampler between epochs; the library's sampler starts over by
+    # itself once num_sampled == num_examples -- the very state the program's reset creates -- so 2 x rows picks in one go are the same list.
+    order = sampler_order(prog, str(cwd / "data" / "mnist" / "mnist_train.csv"), epochs * rows, str(cwd))
     want, lines = oracle_training(ora, p0, lab, px, order, batch, epochs)
     for e, (acc, loss) in enumerate(lines):
         assert got_lines[e].startswith(f"Epoch {e}:\tAvg accuracy: ")
