@@ -287,10 +287,11 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	if (e != hipSuccess) { delete dp; return hip_fail(e, "hipExtMallocWithFlags(fine-grained exchange buffer)"); }
 	dp->flags_uncached = hipExtMallocWithFlags(&f, 4096, hipDeviceMallocUncached) == hipSuccess;
 	if (!dp->flags_uncached) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained); }
-	if (e == hipSuccess) e = hipMemset(p, 0, dp->bytes);
-	if (e == hipSuccess) e = hipMemset(f, 0, 4096);
+	// (on the context's own non-blocking stream, then a device-wide wait: NULL-stream work is not ordered against that stream)
+	if (e == hipSuccess) e = hipMemsetAsync(p, 0, dp->bytes, ctx().stream);
+	if (e == hipSuccess) e = hipMemsetAsync(f, 0, 4096, ctx().stream);
 	if (e == hipSuccess) e = hipMalloc(&s, 64);
-	if (e == hipSuccess) e = hipMemset(s, 0, 64);
+	if (e == hipSuccess) e = hipMemsetAsync(s, 0, 64, ctx().stream);
 	if (e == hipSuccess) e = hipDeviceSynchronize();
 	if (e != hipSuccess) { (void)hipFree(p); if (f) (void)hipFree(f); if (s) (void)hipFree(s); delete dp; return hip_fail(e, "exchange state allocation"); }
 	dp->base = (char*)p; dp->flags = (char*)f; dp->state = (unsigned*)s;
@@ -428,7 +429,8 @@ bla_status bla_dp_status(bla_dp* dp, int* status) {
 	BLA_REQUIRE(dp && status, BLA_ERR_INVALID, "null argument");
 	unsigned s[3];
 	BLA_HIP(hipDeviceSynchronize());
-	BLA_HIP(hipMemcpy(s, dp->state, sizeof s, hipMemcpyDeviceToHost));
+	BLA_HIP(hipMemcpyAsync(s, dp->state, sizeof s, hipMemcpyDeviceToHost, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	*status = (int)s[2];
 	return BLA_OK;
 }

@@ -119,21 +119,28 @@ bla_status bla_mnist_nn_use_buckets(bla_mnist_nn* nn, float* d_params, float* d_
 	for (int i = 0; i < 2; i++)   // recorded data-parallel steps hold the old parameter bucket: drop them, the next dp_step records again
 		if (nn->dp_ready[i]) { (void)hipGraphExecDestroy(nn->dp_exec[i]); (void)hipGraphDestroy(nn->dp_graph[i]); nn->dp_ready[i] = false; }
 	BLA_HIP(hipDeviceSynchronize());
-	BLA_HIP(hipMemcpy(d_params, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToDevice));
+	BLA_HIP(hipMemcpyAsync(d_params, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToDevice, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	nn->params = d_params; nn->grads = d_grads; nn->own_buckets = false;
 	return BLA_OK;
 }
 
 bla_status bla_mnist_nn_set_params(bla_mnist_nn* nn, const float* h_flat) {
 	BLA_REQUIRE(nn && h_flat, BLA_ERR_INVALID, "null argument");
-	BLA_HIP(hipMemcpy(nn->params, h_flat, nn->count * sizeof(float), hipMemcpyHostToDevice));
+	// On the context's own (non-blocking) stream and waited for: a NULL-stream hipMemcpy from pageable memory returns once the bytes are
+	// staged, its DMA is only ordered against blocking streams -- a step launched right behind it on the context stream read stale weights
+	// (seen from the C trainer, whose host side is fast enough to get there first).
+	BLA_HIP(hipDeviceSynchronize());
+	BLA_HIP(hipMemcpyAsync(nn->params, h_flat, nn->count * sizeof(float), hipMemcpyHostToDevice, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	return BLA_OK;
 }
 
 bla_status bla_mnist_nn_get_params(bla_mnist_nn* nn, float* h_flat) {
 	BLA_REQUIRE(nn && h_flat, BLA_ERR_INVALID, "null argument");
 	BLA_HIP(hipDeviceSynchronize());
-	BLA_HIP(hipMemcpy(h_flat, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToHost));
+	BLA_HIP(hipMemcpyAsync(h_flat, nn->params, nn->count * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	return BLA_OK;
 }
 
@@ -345,15 +352,16 @@ bla_status bla_mnist_nn_metrics_read(bla_mnist_nn* nn, double* loss_sum, long lo
 	BLA_REQUIRE(nn->metrics_on, BLA_ERR_INVALID, "bla_mnist_nn_metrics_enable has not run");
 	BLA_HIP(hipDeviceSynchronize());
 	std::vector<double> l(nn->batch); std::vector<unsigned> c(nn->batch);
-	BLA_HIP(hipMemcpy(l.data(), nn->m_loss, nn->batch * sizeof(double), hipMemcpyDeviceToHost));
-	BLA_HIP(hipMemcpy(c.data(), nn->m_correct, nn->batch * sizeof(unsigned), hipMemcpyDeviceToHost));
+	BLA_HIP(hipMemcpyAsync(l.data(), nn->m_loss, nn->batch * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+	BLA_HIP(hipMemcpyAsync(c.data(), nn->m_correct, nn->batch * sizeof(unsigned), hipMemcpyDeviceToHost, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	double ls = 0; long long cs = 0;
 	for (int i = 0; i < nn->batch; i++) { ls += l[i]; cs += c[i]; }   // column order
 	*loss_sum = ls; *num_correct = cs;
 	if (reset) {
-		BLA_HIP(hipMemset(nn->m_loss, 0, nn->batch * sizeof(double)));
-		BLA_HIP(hipMemset(nn->m_correct, 0, nn->batch * sizeof(unsigned)));
-		BLA_HIP(hipDeviceSynchronize());
+		BLA_HIP(hipMemsetAsync(nn->m_loss, 0, nn->batch * sizeof(double), ctx().stream));
+		BLA_HIP(hipMemsetAsync(nn->m_correct, 0, nn->batch * sizeof(unsigned), ctx().stream));
+		BLA_HIP(hipStreamSynchronize(ctx().stream));
 	}
 	return BLA_OK;
 }
