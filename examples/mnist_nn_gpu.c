@@ -29,7 +29,7 @@
  *
  *   gcc -std=c99 -O2 -I include -I big-linear-algebra_amd/lib examples/mnist_nn_gpu.c -o mnist_nn_gpu \
  *       -L big-linear-algebra_amd/lib -l:libbla_host.so -L big-linear-algebra_amd/csrc -l:libbla_hip.so -lm */
-#define _POSIX_C_SOURCE 199309L
+#define _XOPEN_SOURCE 600      /* clock_gettime, initstate / setstate */
 #include "bla.h"
 #include "csv.h"
 #include "mnist_csv2.h"
@@ -54,6 +54,16 @@ static const char* kFiles[6] = {"weights_1.csv", "biases_1.csv", "weights_2.csv"
 		}                                                                                        \
 	} while (0)
 
+/* The reference's draws come from libc rand() after srand(42) (model/mnist_nn.c:513).  The GPU runtime and the collective library are
+ * free to call rand() / srand() themselves (observed: the example order changed from run to run once the device was initialised), so this
+ * program keeps the stream the REFERENCE would see in a state array of its own -- glibc's rand() is random() on the current state, and
+ * initstate(42, 128-byte array) is exactly srand(42) -- and switches to it only around its own draws. */
+static char g_rng_mine[128];
+static char* g_rng_others;
+static void rng_begin(void) { g_rng_others = setstate(g_rng_mine); }
+static void rng_end(void) { (void)setstate(g_rng_others); }
+static void rng_seed(unsigned seed) { g_rng_others = initstate(seed, g_rng_mine, sizeof g_rng_mine); rng_end(); }
+
 static const char* env_or(const char* name, const char* fallback) { const char* v = getenv(name); return v && *v ? v : fallback; }
 static void weight_path(char* out, size_t n, int which) { snprintf(out, n, "%s/%s", env_or("BLA_MNIST_WEIGHTS", "data/mnist_nn"), kFiles[which]); }
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -61,6 +71,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 /* ---- init: model/mnist_nn.c:97-142 (same order of rand() draws, same float expressions) ---------------------------------------- */
 static void init(void) {
 	char path[512];
+	rng_begin();
 	const int fan_in[3] = {N0, N1, N2}, fan_out[3] = {N1, N2, N3};
 	for (int l = 0; l < 3; l++) {
 		const int count = fan_in[l] * fan_out[l];
@@ -77,6 +88,7 @@ static void init(void) {
 		write_csv_contents(path, b, 1, fan_out[l]);
 		free(b);
 	}
+	rng_end();
 }
 
 static size_t param_count(void) {
@@ -221,8 +233,29 @@ static void train(int num_epochs, int batch, int colsum_mode) {
 		memset(store.sampled, 0, (size_t)N);                             /* :189-191 */
 		store.num_sampled = 0;
 		const double t0 = now_s();
+		rng_begin();
 		int* order = take_order(&store, N);                              /* the N draws of :205, in order */
+		rng_end();
 		for (int r = 0; r < gpus; r++) { use(&rep[r]); CHECK(bla_memcpy_h2d(rep[r].d_order, order, (size_t)N * sizeof(int), NULL)); CHECK(bla_stream_sync(NULL)); }
+		if (getenv("BLA_MNIST_SELFCHECK")) {     /* debugging aid: what the device holds against what the host sent */
+			use(&rep[0]);
+			float* back = malloc((size_t)N * N0 * sizeof(float));
+			CHECK(bla_memcpy_d2h(back, rep[0].d_X, (size_t)N * N0 * sizeof(float), NULL)); CHECK(bla_stream_sync(NULL));
+			fprintf(stderr, "[selfcheck] dataset %s\n", memcmp(back, store.X, (size_t)N * N0 * sizeof(float)) ? "DIFFERS" : "ok");
+			int* ob = malloc((size_t)N * sizeof(int));
+			CHECK(bla_memcpy_d2h(ob, rep[0].d_order, (size_t)N * sizeof(int), NULL)); CHECK(bla_stream_sync(NULL));
+			fprintf(stderr, "[selfcheck] order %s, head %d %d %d %d\n", memcmp(ob, order, (size_t)N * sizeof(int)) ? "DIFFERS" : "ok", order[0], order[1], order[2], order[3]);
+			float* pb = malloc(param_count() * sizeof(float));
+			CHECK(bla_mnist_nn_get_params(rep[0].nn, pb));
+			fprintf(stderr, "[selfcheck] params %s\n", i == 0 && memcmp(pb, flat, param_count() * sizeof(float)) ? "DIFFERS" : "ok");
+			CHECK(bla_mnist_nn_gather_batch(rep[0].nn, NULL, rep[0].d_X, rep[0].d_y, N, rep[0].d_order));
+			float* xb = malloc((size_t)N0 * per * sizeof(float));
+			CHECK(bla_memcpy_d2h(xb, bla_mnist_nn_input(rep[0].nn), (size_t)N0 * per * sizeof(float), NULL)); CHECK(bla_stream_sync(NULL));
+			int bad = 0;
+			for (int p = 0; p < N0; p++) for (int k = 0; k < per && k < N; k++) bad += xb[(size_t)p * per + k] != store.X[(size_t)p * N + order[k]];
+			fprintf(stderr, "[selfcheck] gathered batch: %d mismatches\n", bad);
+			free(back); free(ob); free(pb); free(xb);
+		}
 		for (int j = 0; j < num_batches; j++) {
 			const int in_this_batch = j == num_batches - 1 ? last : batch;
 			for (int r = 0; r < gpus; r++) {       /* every replica's launches are queued before any of them is waited for */
@@ -230,6 +263,7 @@ static void train(int num_epochs, int batch, int colsum_mode) {
 				bla_mnist_nn* nn = in_this_batch == batch ? rep[r].nn : rep[r].tail;
 				const int mine = in_this_batch / gpus;
 				CHECK(bla_mnist_nn_gather_batch(nn, NULL, rep[r].d_X, rep[r].d_y, N, rep[r].d_order + (size_t)j * batch + (size_t)r * mine));
+				if (getenv("BLA_MNIST_SYNC_AFTER_GATHER")) CHECK(bla_stream_sync(NULL));
 				if (gpus == 1) CHECK(bla_mnist_nn_fused_step(nn, NULL, NULL, NULL, epoch_learn_rate, colsum_mode));
 				else CHECK(bla_mnist_nn_dp_step_direct(nn, rep[r].dp, NULL, epoch_learn_rate, colsum_mode));
 			}
@@ -276,7 +310,9 @@ static void run(int num_predictions) {
 	if (num_predictions == -1 || num_predictions > store.num_examples) num_predictions = store.num_examples;     /* :421-423 */
 	printf("Running predictions for %d digits...", num_predictions);
 	fflush(stdout);
+	rng_begin();
 	int* order = take_order(&store, num_predictions);                     /* the draws of :435 */
+	rng_end();
 	CHECK(bla_init(0));
 	Replica rep;
 	memset(&rep, 0, sizeof rep);
@@ -314,7 +350,7 @@ static void run(int num_predictions) {
 }
 
 int main(int argc, char** argv) {      /* model/mnist_nn.c:512-536, plus the batch size / col-sum mode arguments */
-	srand(42);
+	rng_seed(42);                      /* srand(42), :513 */
 	if (argc < 2) {
 		printf("Please supply an argument, options:\n\trun [<num predictions>]\n\ttrain <num epochs> [<batch size> [as-written]]\n\tinit\n");
 		exit(1);
@@ -338,6 +374,7 @@ int main(int argc, char** argv) {      /* model/mnist_nn.c:512-536, plus the bat
 		MnistCSV store;
 		open_store(&store, argv[2]);
 		const int draws = atoi(argv[3]);
+		rng_begin();
 		if (strcmp(argv[4], "fast") == 0) {
 			int* order = take_order(&store, draws);
 			for (int d = 0; d < draws; d++) printf("%d\n", order[d]);
@@ -345,6 +382,7 @@ int main(int argc, char** argv) {      /* model/mnist_nn.c:512-536, plus the bat
 		} else {
 			for (int d = 0; d < draws; d++) printf("%d\n", (int)(get_random_data_take(&store).X - store.X));
 		}
+		rng_end();
 	} else {
 		printf("Unrecognized argument, options:\n\trun [<num predictions>]\n\ttrain <num epochs> [<batch size> [as-written]]\n\tinit\n");
 		exit(1);
