@@ -398,3 +398,16 @@ def test_layer_h_mlp_against_reference_run(host):
     for l in reversed(layers[1:]):
         host.free_layer_data(l)
     host.free_matrix(layers[0].nodes)
+
+
+@gpu
+def test_library_leaves_the_callers_rand_stream_alone(tmp_path, pkg):
+    """tests/c/rand_stream.c: srand(42) ... rand() around bla_init, allocations, copies, a launch, a second context, the exchange object
+    and an RCCL communicator -- the draws the reference's programs make between library calls (sampler, dropout) must be the seeded ones."""
+    pkg.build_native()
+    exe = str(tmp_path / "rand_stream")
+    r = _cc(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "rand_stream.c"), "-o", exe,
+             "-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}"])
+    assert r.returncode == 0, r.stderr
+    r = _cc([exe])
+    assert r.returncode == 0 and r.stdout.count(": ok") == 8, r.stdout + r.stderr
