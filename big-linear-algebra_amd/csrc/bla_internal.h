@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <cstdlib>
 #include "../../include/bla.h"
 
 namespace bla {
@@ -59,6 +60,19 @@ unsigned long long dp_identity(const bla_dp* dp);
 // one and the one for an epoch's last, shorter batch -- may share an exchange object: the parity must alternate over ALL their steps)
 int dp_parity(const bla_dp* dp);
 void dp_advance(bla_dp* dp);
+
+// The callers of this library are the reference's C programs: they seed libc rand() once (srand(42), model/mnist_nn.c:513) and draw from it
+// between library calls (MNIST sampler, U-Net dropout).  HIP runtime initialisation and RCCL communicator set-up draw from / reseed rand()
+// themselves (measured: tests/c/rand_stream.c), which would shift the program's stream against the reference's CPU run.  glibc's rand() is
+// random() on the current state array: park the caller's state while those calls run and put it back afterwards.
+struct RandStreamGuard {
+	char scratch[128];
+	char* saved;
+	RandStreamGuard() { saved = initstate(1u, scratch, sizeof scratch); }
+	~RandStreamGuard() { (void)setstate(saved); }
+	RandStreamGuard(const RandStreamGuard&) = delete;
+	RandStreamGuard& operator=(const RandStreamGuard&) = delete;
+};
 
 #define BLA_HIP(call)                                               \
 	do {                                                            \

@@ -32,6 +32,7 @@ extern "C" {
 
 bla_status bla_dp_rccl_unique_id(void* id128) {
 	BLA_REQUIRE(id128, BLA_ERR_INVALID, "null argument");
+	RandStreamGuard keep_callers_rand_stream;   // RCCL's bootstrap draws from rand()
 	static_assert(sizeof(ncclUniqueId) == BLA_RCCL_ID_BYTES, "unique id size");
 	ncclUniqueId id;
 	BLA_NCCL(ncclGetUniqueId(&id));
@@ -44,6 +45,7 @@ bla_status bla_dp_rccl_init(bla_rccl** out, const void* id128, int rank, int wor
 	if (st) return st;
 	BLA_REQUIRE(out && id128, BLA_ERR_INVALID, "null argument");
 	BLA_REQUIRE(world >= 1 && rank >= 0 && rank < world, BLA_ERR_INVALID, "rank %d / world %d", rank, world);
+	RandStreamGuard keep_callers_rand_stream;
 	ncclUniqueId id;
 	memcpy(&id, id128, sizeof id);
 	BLA_HIP(hipSetDevice(ctx().device));
@@ -56,6 +58,7 @@ bla_status bla_dp_rccl_init(bla_rccl** out, const void* id128, int rank, int wor
 
 bla_status bla_dp_rccl_destroy(bla_rccl* c) {
 	if (!c) return BLA_OK;
+	RandStreamGuard keep_callers_rand_stream;
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	ncclResult_t r = ncclCommDestroy(c->comm);
@@ -70,6 +73,7 @@ bla_status bla_dp_rccl_allreduce_f32(bla_rccl* c, void* stream, float* d_buf, si
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(c && d_buf, BLA_ERR_INVALID, "null argument");
+	RandStreamGuard keep_callers_rand_stream;
 	BLA_NCCL(ncclAllReduce(d_buf, d_buf, count, ncclFloat, ncclSum, c->comm, pick_stream(stream)));
 	return BLA_OK;
 }

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(1024) mfma_rate_16x16_kernel(int iters, float*
 extern "C" {
 
 int bla_device_count(void) {
+	RandStreamGuard keep_callers_rand_stream;
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
@@ -106,6 +107,7 @@ int bla_device_count(void) {
 
 // create stream / counters of one context on `device` (the caller holds g_mu)
 static bla_status open_context(Context& c, int device) {
+	RandStreamGuard keep_callers_rand_stream;   // the first HIP calls of a process initialise the runtime, which draws from rand()
 	int n = bla_device_count();
 	if (n <= 0) {
 		set_error("no HIP device visible (hipGetDeviceCount = %d); this library has no CPU path", n);
@@ -133,6 +135,7 @@ static bla_status open_context(Context& c, int device) {
 
 static void close_context(Context& c) {
 	if (!c.ready) return;
+	RandStreamGuard keep_callers_rand_stream;
 	(void)hipSetDevice(c.device);
 	(void)hipDeviceSynchronize();
 	(void)hipStreamDestroy(c.stream);
