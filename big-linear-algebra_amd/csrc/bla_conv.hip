@@ -15,6 +15,7 @@
 //     around its two products (lib/conv.c:221-227) disappear into the GEMM's transa/transb.
 #include "bla_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -74,6 +75,51 @@ __global__ void __launch_bounds__(kThreads) col2im_s1_kernel(const float* __rest
 		}
 		out[e] = acc;
 	}
+}
+
+// Stride s > 1: the reference's _col2im is undefined there (it walks the IMAGE grid with out_row = i*stride + k: out of bounds).
+// The INTENDED operation is the adjoint of _im2col (lib/conv.c:58-74): out[c][y][x] = sum over output pixels (i, j) and taps (p, q) with
+// i*s + p - pt == y, j*s + q - pl == x of cols[(i, j)][c, p, q], pinned by <im2col(x), v> == <x, col2im(v)> (tests/test_conv_gpu.py).
+// Same gather form and the same order of additions as the stride-1 kernel above (ascending (i, j)).
+__global__ void __launch_bounds__(kThreads) col2im_adjoint_kernel(const float* __restrict__ cols, float* __restrict__ out, int h, int w, int k, int c_n,
+                                                                   int s, int ho, int wo, int pt, int pl) {
+	const int kk = k * k, roww = kk * c_n;
+	const size_t total = (size_t)c_n * h * w;
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		int xx = (int)(e % w), yy = (int)((e / w) % h), c = (int)(e / ((size_t)w * h));
+		float acc = 0.f;
+		for (int p = k - 1; p >= 0; p--) {
+			int iy = yy + pt - p;
+			if (iy < 0 || iy % s) continue;
+			int i = iy / s;
+			if (i >= ho) continue;
+			for (int q = k - 1; q >= 0; q--) {
+				int jx = xx + pl - q;
+				if (jx < 0 || jx % s) continue;
+				int j = jx / s;
+				if (j >= wo) continue;
+				acc += cols[((size_t)i * wo + j) * roww + c * kk + p * k + q];
+			}
+		}
+		out[e] = acc;
+	}
+}
+
+// dst [planes][(Ho-1)*s+1][(Wo-1)*s+1] = src [planes][Ho][Wo] with s-1 zeros between neighbours: the data gradient of a stride-s convolution
+// is the stride-1 convolution of this dilated gradient with the flipped kernels
+__global__ void __launch_bounds__(kThreads) dilate_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int ho, int wo, int s, int hd, int wd) {
+	const size_t total = (size_t)planes * hd * wd;
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		int x = (int)(e % wd); size_t t = e / wd;
+		int y = (int)(t % hd); size_t pc = t / hd;
+		dst[e] = (y % s == 0 && x % s == 0) ? src[(pc * ho + y / s) * wo + x / s] : 0.f;
+	}
+}
+
+// BLA_STRICT_REFERENCE=1: operations the reference leaves undefined are refused instead of given their intended meaning
+static bool strict_reference() {
+	static const bool v = [] { const char* e = getenv("BLA_STRICT_REFERENCE"); return e && e[0] == '1'; }();
+	return v;
 }
 
 // ---- group norm, lib/norm.c (quirk Q3 kept: epsilon is integer 0 and "stdev" is the variance) --------------
@@ -815,13 +861,17 @@ bla_status bla_col2im_f32(void* stream, const float* d_cols, float* d_out, int h
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(h > 0 && w > 0 && k > 0 && c_n > 0 && stride > 0, BLA_ERR_INVALID, "bad col2im shape h=%d w=%d k=%d c=%d s=%d", h, w, k, c_n, stride);
-	if (stride != 1) {
+	if (stride != 1 && strict_reference()) {
 		set_error("_col2im iterates the image grid with out_row = i*stride + k (lib/conv.c:80-135): out of bounds for stride %d, undefined in the reference", stride);
 		return BLA_ERR_UNDEFINED;
 	}
 	BLA_REQUIRE(d_cols && d_out, BLA_ERR_INVALID, "null operand");
-	Geometry g = same_geometry(h, w, k, 1);
-	hipLaunchKernelGGL(col2im_s1_kernel, dim3(grid_for((size_t)c_n * h * w)), dim3(kThreads), 0, pick_stream(stream), d_cols, d_out, h, w, k, c_n, g.pt, g.pl);
+	Geometry g = same_geometry(h, w, k, stride);
+	if (stride == 1)
+		hipLaunchKernelGGL(col2im_s1_kernel, dim3(grid_for((size_t)c_n * h * w)), dim3(kThreads), 0, pick_stream(stream), d_cols, d_out, h, w, k, c_n, g.pt, g.pl);
+	else   // the intended operation: the adjoint of _im2col
+		hipLaunchKernelGGL(col2im_adjoint_kernel, dim3(grid_for((size_t)c_n * h * w)), dim3(kThreads), 0, pick_stream(stream), d_cols, d_out, h, w, k, c_n, stride,
+		                   g.ho, g.wo, g.pt, g.pl);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -871,12 +921,14 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
                                  float* d_del_kern, float* d_del_col, float* d_del_x, int h, int w, int k, int c_in, int f_n, int stride) {
 	bla_status st = require_ready();
 	if (st) return st;
-	if (stride != 1) {
+	if (stride != 1 && strict_reference()) {
 		set_error("conv_ddx is undefined for stride %d: _col2im is only valid for stride 1 (lib/conv.c:80-135)", stride);
 		return BLA_ERR_UNDEFINED;
 	}
 	BLA_REQUIRE(d_del_y && d_im2col && d_kmat && d_del_q && d_del_kmat && d_del_kern && d_del_col && d_del_x, BLA_ERR_INVALID, "null operand");
-	const int hw = h * w, kkc = k * k * c_in;
+	// h, w are the INPUT's; del_y is [F][Ho][Wo] (stride 1: the same size -- the only case the reference defines)
+	const Geometry gm = same_geometry(h, w, k, stride);
+	const int hw = gm.ho * gm.wo, kkc = k * k * c_in;
 	st = bla_reshape_matrix_channels_f32(stream, d_del_q, d_del_y, f_n, hw);                 // del_Q [HW x F] <- del_Y [F x HW]
 	if (st) return st;
 	// del_kernel_matrix [kkC x F] = im2col^T . del_Q          (lib/conv.c:221-222 without the transpose copies)
@@ -887,7 +939,7 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
 	// del_input_matrix [HW x kkC] = del_Q . kernel_matrix^T      (lib/conv.c:225-226)
 	st = bla_gemm_f32(stream, 0, 1, hw, kkc, f_n, d_del_q, f_n, d_kmat, f_n, d_del_col, kkc, nullptr);
 	if (st) return st;
-	return bla_col2im_f32(stream, d_del_col, d_del_x, h, w, k, c_in, 1);                      // lib/conv.c:228
+	return bla_col2im_f32(stream, d_del_col, d_del_x, h, w, k, c_in, stride);                 // lib/conv.c:228
 }
 
 /* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
@@ -965,7 +1017,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 	}
 	if (d_del_x) {
-		if (stride != 1) {
+		if (stride != 1 && strict_reference()) {
 			set_error("the data gradient is undefined in the reference for stride %d (_col2im, lib/conv.c:80-135)", stride);
 			return BLA_ERR_UNDEFINED;
 		}
@@ -973,13 +1025,28 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		int total = f_n * c_in * k * k;
 		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
 		BLA_HIP(hipGetLastError());
-		ConvArgs a;   // image = del_y [F][H][W], "input channels" = F, pads mirrored: k-1-pt, k-1-pl
-		a.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
+		// Stride s > 1 (the intended adjoint; the reference is undefined there): the same stride-1 convolution over del_y with s-1 zeros
+		// put between its pixels, [F][(Ho-1)s+1][(Wo-1)s+1] -- the U-Net's three down-convolutions (model/cifar_unet.c:1105,1111,1115).
+		const float* src = d_del_y;
+		int hd = h, wd = w;
+		size_t src_sz = y_sz;
+		if (stride != 1) {
+			hd = (gm.ho - 1) * stride + 1; wd = (gm.wo - 1) * stride + 1;
+			src_sz = (size_t)f_n * hd * wd;
+			void* ws;
+			st = ensure_workspace2(src_sz * batch * sizeof(float), &ws);
+			if (st) return st;
+			hipLaunchKernelGGL(dilate_kernel, dim3(grid_for(src_sz * batch)), dim3(kThreads), 0, s, d_del_y, (float*)ws, batch * f_n, gm.ho, gm.wo, stride, hd, wd);
+			BLA_HIP(hipGetLastError());
+			src = (const float*)ws;
+		}
+		ConvArgs a;   // image = del_y [F][H][W] (or its dilated form), "input channels" = F, pads mirrored: k-1-pt, k-1-pl
+		a.g = ConvGeom{hd, wd, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
 		st = get_table(s, a.g, &a.tab);
 		if (st) return st;
-		a.A = d_scratch; a.lda = k * k * f_n; a.img = d_del_y; a.out = d_del_x; a.ldo = h * w;
+		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
-		st = launch_implicit<CONV_FWD>(s, a, batch, y_sz, x_sz, 0);
+		st = launch_implicit<CONV_FWD>(s, a, batch, src_sz, x_sz, 0);
 		if (st) return st;
 	}
 	return BLA_OK;

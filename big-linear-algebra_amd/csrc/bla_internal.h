@@ -15,6 +15,8 @@ struct Context {
 	hipStream_t stream = nullptr;
 	void* workspace = nullptr;      // grow-only scratch (split-K slabs, reductions)
 	size_t workspace_bytes = 0;
+	void* workspace2 = nullptr;     // a second grow-only scratch for operands that must survive a kernel which uses the first (dilated gradients)
+	size_t workspace2_bytes = 0;
 	unsigned* tile_counters = nullptr;   // 16384 arrival counters for in-launch split-K, zero between launches
 	int num_cus = 0;
 	char arch[64] = {0};
@@ -27,6 +29,7 @@ bla_status hip_fail(hipError_t e, const char* what);
 bla_status require_ready();
 // Scratch of at least `bytes` (device); valid until the next ensure_workspace call that grows it.
 bla_status ensure_workspace(size_t bytes, void** out);
+bla_status ensure_workspace2(size_t bytes, void** out);
 // out[i] = sum_{j<len} m[i*stride + j], i < count (bla_elementwise.hip)
 bla_status window_sum(void* stream, const float* m, int count, int len, int stride, float* out);
 inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : ctx().stream; }

@@ -53,6 +53,22 @@ bla_status ensure_workspace(size_t bytes, void** out) {
 	return BLA_OK;
 }
 
+bla_status ensure_workspace2(size_t bytes, void** out) {
+	Context& c = ctx();
+	if (bytes > c.workspace2_bytes) {
+		if (c.workspace2) {
+			BLA_HIP(hipDeviceSynchronize());
+			BLA_HIP(hipFree(c.workspace2));
+			c.workspace2 = nullptr;
+			c.workspace2_bytes = 0;
+		}
+		BLA_HIP(hipMalloc(&c.workspace2, bytes));
+		c.workspace2_bytes = bytes;
+	}
+	*out = c.workspace2;
+	return BLA_OK;
+}
+
 }  // namespace bla
 
 using namespace bla;
@@ -140,6 +156,7 @@ static void close_context(Context& c) {
 	(void)hipDeviceSynchronize();
 	(void)hipStreamDestroy(c.stream);
 	if (c.workspace) (void)hipFree(c.workspace);
+	if (c.workspace2) (void)hipFree(c.workspace2);
 	if (c.tile_counters) (void)hipFree(c.tile_counters);
 	c = Context();
 }

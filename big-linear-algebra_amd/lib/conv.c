@@ -12,8 +12,8 @@
  *    from the stale output and output is never produced.  Default here: the intended composition
  *    (GEMM result reaches output, product keeps the GEMM result).  BLA_STRICT_REFERENCE=1: literal behaviour.
  *  - conv_ddx(): likewise the first step as written overwrites del_Y from the stale del_Q; default feeds del_Y
- *    into del_Q.  Stride must be 1: the reference's _col2im indexes out of bounds otherwise and
- *    this layer refuses instead.
+ *    into del_Q.  The reference's _col2im indexes out of bounds for stride != 1: this layer then computes the
+ *    intended gradient (the adjoint of _im2col); BLA_STRICT_REFERENCE=1 refuses instead.
  */
 #include "conv.h"
 #include "bla_host.h"
@@ -62,7 +62,7 @@ void _im2col(Matrix* in, Matrix* out, int kernel_size, int in_channels, int stri
 	bla_host_down(out->data, dout, n);
 }
 
-/* reference lib/conv.c:80-135 (stride 1 only: anything else is out of bounds there, refused here) */
+/* reference lib/conv.c:80-135 (defined for stride 1; other strides: the adjoint of _im2col, refused under BLA_STRICT_REFERENCE=1) */
 void _col2im(Matrix* in, Matrix* out, int kernel_size, int out_channels, int stride) {
 	float* dcols = bla_host_up(S_IM2COL, in->data, (size_t)in->rows * in->cols);
 	float* dout = bla_host_buf(S_X, (size_t)out[0].rows * out[0].cols * out_channels);
@@ -138,12 +138,17 @@ void conv(Matrix* X, Matrix** kernels, ConvData* data, int in_channels, int out_
 }
 
 /* reference lib/conv.c:214-229.  Workspaces come from grad_data exactly as there: product = del_Q,
- * kernel_matrix = del_kernels_matrix, im2col = del_input_matrix. */
+ * kernel_matrix = del_kernels_matrix, im2col = del_input_matrix.
+ * Stride 1 is the only case the reference defines (its _col2im walks out of bounds otherwise).  For other strides this layer
+ * computes the INTENDED gradient -- del_input = adjoint of _im2col applied to del_Q . kernel_matrix^T, with the input's size taken from
+ * del_input -- unless BLA_STRICT_REFERENCE=1, which refuses. */
 void conv_ddx(Matrix* del_Y, ConvData* data, ConvData* grad_data, Matrix** del_kernels, Matrix* del_input, int in_channels, int stride) {
-	const int k = del_kernels[0][0].cols, h = del_Y[0].rows, w = del_Y[0].cols;
+	const int k = del_kernels[0][0].cols;
+	const int ho = del_Y[0].rows, wo = del_Y[0].cols;                      /* output pixels */
+	const int h = stride == 1 ? ho : del_input[0].rows, w = stride == 1 ? wo : del_input[0].cols;
 	const int f_n = grad_data->product->cols;
-	const size_t hw = (size_t)h * w, kkc = (size_t)k * k * in_channels;
-	if (stride != 1) {
+	const size_t hw = (size_t)ho * wo, kkc = (size_t)k * k * in_channels;
+	if (stride != 1 && bla_host_strict()) {
 		fflush(stdout);
 		fprintf(stderr, "conv_ddx: stride %d is undefined in the reference (_col2im is only valid for stride 1, lib/conv.c:80-135)\n", stride);
 		exit(1);
@@ -160,8 +165,8 @@ void conv_ddx(Matrix* del_Y, ConvData* data, ConvData* grad_data, Matrix** del_k
 	float* ddkm = bla_host_buf(S_AUX0, kkc * f_n);
 	float* ddk = bla_host_buf(S_KERN, kkc * f_n);
 	float* ddcol = bla_host_buf(S_AUX1, hw * kkc);
-	float* ddx = bla_host_buf(S_X, hw * in_channels);
-	BLA_TRY(bla_conv_backward_f32(NULL, ddy, dim, dkm, ddq, ddkm, ddk, ddcol, ddx, h, w, k, in_channels, f_n, 1));
+	float* ddx = bla_host_buf(S_X, (size_t)h * w * in_channels);
+	BLA_TRY(bla_conv_backward_f32(NULL, ddy, dim, dkm, ddq, ddkm, ddk, ddcol, ddx, h, w, k, in_channels, f_n, stride));
 	if (!bla_host_strict()) bla_host_down(grad_data->product->data, ddq, hw * f_n);   /* strict: del_Q is left as it was */
 	bla_host_down(grad_data->kernel_matrix->data, ddkm, kkc * f_n);
 	bla_host_down(grad_data->im2col->data, ddcol, hw * kkc);

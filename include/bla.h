@@ -201,7 +201,9 @@ BLA_API bla_status bla_softmax_cols_grad_f32(void* stream, float* d, int rows, i
  * product [Ho*Wo][F], output [F][Ho][Wo].  TF "SAME" padding, Ho = ceil((float)H/stride) (lib/conv.c:13-28,55-56). */
 BLA_API bla_status bla_conv_out_hw(int h, int w, int stride, int* ho, int* wo);
 BLA_API bla_status bla_im2col_f32(void* stream, const float* d_x, float* d_out, int h, int w, int k, int c_in, int stride);       /* _im2col, lib/conv.c:8-77 */
-/* _col2im, lib/conv.c:80-135: defined for stride 1 only (returns BLA_ERR_UNDEFINED otherwise) */
+/* _col2im, lib/conv.c:80-135: the reference is defined for stride 1 only (it walks the image grid instead of the output grid).
+ * Other strides give the INTENDED operation, the adjoint of _im2col (d_cols is [Ho*Wo][k*k*C], d_out [C][h][w]); with BLA_STRICT_REFERENCE=1
+ * in the environment they return BLA_ERR_UNDEFINED instead. */
 BLA_API bla_status bla_col2im_f32(void* stream, const float* d_cols, float* d_out, int h, int w, int k, int c_n, int stride);
 BLA_API bla_status bla_kernels_to_matrix_f32(void* stream, const float* d_kern, float* d_mat, int f_n, int c_n, int k);          /* _reshape_kernels_matrix, lib/conv.c:138-153 */
 BLA_API bla_status bla_matrix_to_kernels_f32(void* stream, const float* d_mat, float* d_kern, int f_n, int c_n, int k);          /* _reshape_matrix_kernels, lib/conv.c:156-171 */
@@ -213,14 +215,17 @@ BLA_API bla_status bla_reshape_matrix_channels_f32(void* stream, float* d_matrix
  * from the stale output and never writes output -- the host layer offers that literal mode too). */
 BLA_API bla_status bla_conv_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_im2col, float* d_kmat, float* d_product,
                                         float* d_output, int h, int w, int k, int c_in, int f_n, int stride);
-/* conv_ddx(), lib/conv.c:214-229, intended composition; stride must be 1. */
+/* conv_ddx(), lib/conv.c:214-229, intended composition.  h, w are the INPUT's size; del_y is [F][Ho][Wo].  Stride 1 is the reference's only
+ * defined case; other strides use the adjoint _col2im above (BLA_STRICT_REFERENCE=1: BLA_ERR_UNDEFINED). */
 BLA_API bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float* d_im2col, const float* d_kmat, float* d_del_q,
                                          float* d_del_kmat, float* d_del_kern, float* d_del_col, float* d_del_x, int h, int w, int k, int c_in,
                                          int f_n, int stride);
 /* Implicit-GEMM convolution for device-resident callers: the im2col matrix is gathered inside the MFMA kernel and
  * never written (no ConvData workspaces).  Values equal conv()'s `output` / conv_ddx()'s del_kernels and del_input
- * (lib/conv.c:205-229, intended composition).  Forward and weight gradient accept any stride; the data gradient is
- * stride-1 only, like the reference.  d_scratch: F*C*k*k floats, needed only when d_del_x != NULL. */
+ * (lib/conv.c:205-229, intended composition).  Any stride.  The data gradient at stride != 1 (undefined in the reference) is
+ * the adjoint of the forward map -- the stride-1 convolution of the zero-dilated del_y with the flipped kernels -- as the U-Net's three
+ * down-convolutions need it (model/cifar_unet.c:1105,1111,1115; backward :1412,1420,1430); BLA_STRICT_REFERENCE=1 refuses it
+ * (BLA_ERR_UNDEFINED).  d_scratch: F*C*k*k floats, needed only when d_del_x != NULL. */
 BLA_API bla_status bla_conv2d_forward_f32(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride);
 BLA_API bla_status bla_conv2d_backward_f32(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern,
                                            float* d_del_x, float* d_scratch, int h, int w, int k, int c_in, int f_n, int stride);

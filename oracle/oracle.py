@@ -201,6 +201,22 @@ def col2im(cols, c, h, w, k, s=1):
     return out if ok else None
 
 
+def col2im_adjoint(cols, c, h, w, k, s):
+    """The INTENDED _col2im for any stride: the adjoint of _im2col (lib/conv.c:58-74), out[c][i*s+p-pt][j*s+q-pl] += cols[(i,j)][c,p,q].
+    The reference's own _col2im (lib/conv.c:80-135) walks the image grid instead of the output grid and is only defined for s == 1, where
+    the two coincide; beyond that this restatement is pinned by <im2col(x), v> == <x, col2im_adjoint(v)> (tests).  numpy, small cases."""
+    cols = np.asarray(cols)
+    ho, wo = out_hw(h, w, s)
+    vpad = max(int((np.ceil(np.float32(h) / s) - 1) * s + k - h), 0); hpad = max(int((np.ceil(np.float32(w) / s) - 1) * s + k - w), 0)
+    pt, pl = vpad // 2, hpad // 2
+    pad = np.zeros((c, h + vpad + k, w + hpad + k), cols.dtype)
+    v = cols.reshape(ho, wo, c, k, k)
+    for i in range(ho):
+        for j in range(wo):
+            pad[:, i * s:i * s + k, j * s:j * s + k] += v[i, j]
+    return np.ascontiguousarray(pad[:, pt:pt + h, pl:pl + w])
+
+
 def kernels_to_matrix(kern):
     kern = _c(kern); f, c, k, _ = kern.shape
     mat = np.empty((k * k * c, f), kern.dtype)

@@ -67,9 +67,32 @@ def test_col2im_and_backward(dev, ora):
         h, w, cin, cout, k, s, seed, x, kern = conv_case(i, cfg)
         hw, kkc = h * w, k * k * cin
         if s != 1:
-            o = dev.empty((cin, h, w))
-            assert dev.lib().bla_col2im_f32(None, dev.zeros((hw, kkc)).ptr, o.ptr, h, w, k, cin, s) == 5     # undefined (Q5)
-            assert dev.lib().bla_conv_backward_f32(None, *([o.ptr] * 9), h, w, k, cin, cout, s) == 5
+            # The reference's _col2im / conv_ddx are undefined here.  Default: the intended operation, the adjoint of _im2col
+            # (BLA_STRICT_REFERENCE=1 refuses: test_strict_reference_refuses_undefined_strides).  Pinned by the adjoint identity and by the
+            # oracle's restatement of that adjoint.
+            ho, wo = ora.out_hw(h, w, s); hwo = ho * wo
+            cols = uniform(seed + 2, (hwo, kkc), -1, 1, F32)
+            o = dev.empty((cin, h, w)).fill_bytes(0xFF); call(dev, "bla_col2im_f32", dev.to_device(cols), o, h, w, k, cin, s)
+            want = ora.col2im_adjoint(cols.astype(np.float64), cin, h, w, k, s)
+            assert np.abs(o.numpy() - want).max() <= 2e-6 * np.abs(cols).max() * k * k
+            xr = uniform(seed + 5, (cin, h, w), -1, 1, F32)
+            imx = dev.empty((hwo, kkc)); call(dev, "bla_im2col_f32", dev.to_device(xr), imx, h, w, k, cin, s)
+            lhs = float((imx.numpy().astype(np.float64) * cols).sum()); rhs = float((xr.astype(np.float64) * o.numpy()).sum())
+            assert abs(lhs - rhs) <= 1e-5 * (np.abs(imx.numpy()).astype(np.float64) * np.abs(cols)).sum()
+            # conv_ddx chain with the input's size h x w and del_y of the output's size
+            fw = ora.conv_intended(x, kern, s)
+            del_y = uniform(seed + 3, (cout, ho, wo), -1, 1, F32)
+            dq, dkm, dkern = dev.empty((hwo, cout)), dev.empty((kkc, cout)), dev.empty((cout, cin, k, k))
+            dcol, dxx = dev.empty((hwo, kkc)), dev.empty((cin, h, w))
+            call(dev, "bla_conv_backward_f32", dev.to_device(del_y), dev.to_device(fw["im2col"]), dev.to_device(fw["kmat"]),
+                 dq, dkm, dkern, dcol, dxx, h, w, k, cin, cout, s)
+            dq64 = ora.reshape_matrix_channels(del_y.astype(np.float64))
+            assert np.array_equal(dq.numpy(), dq64.astype(F32))
+            im64, km64 = fw["im2col"].astype(np.float64), fw["kmat"].astype(np.float64)
+            assert (np.abs(dkm.numpy() - im64.T @ dq64) <= 1e-5 * (np.abs(im64.T) @ np.abs(dq64))).all()
+            dcol64 = dq64 @ km64.T; b2 = (np.abs(dq64) @ np.abs(km64.T)).max()
+            assert (np.abs(dcol.numpy() - dcol64) <= 1e-5 * b2).all()
+            assert (np.abs(dxx.numpy() - ora.col2im_adjoint(dcol64, cin, h, w, k, s)) <= 1e-5 * b2 * k * k).all()
             continue
         cols = uniform(seed + 2, (hw, kkc), -1, 1, F32)
         o = dev.empty((cin, h, w)); call(dev, "bla_col2im_f32", dev.to_device(cols), o, h, w, k, cin, 1)
@@ -169,9 +192,32 @@ def test_implicit_gemm_conv_matches_reference(dev, ora):
             want = ora.matrix_to_kernels(ora.matmul(ora.transpose(fw["im2col"]), dq), cin, k)   # lib/conv.c:221-223
             b1 = (np.abs(fw["im2col"]).T @ np.abs(dq)).max()
             assert (np.abs(dkern.numpy() - want) <= 1e-5 * b1).all()
-            keep = dev.empty((cin, h, w))
-            assert dev.lib().bla_conv2d_backward_f32(None, dev.to_device(del_y).ptr, dx_.ptr, dk_.ptr, None, keep.ptr, keep.ptr,
-                                                     h, w, k, cin, cout, s) == 5                # data gradient: undefined (Q5)
+            # data gradient at stride s: undefined in the reference (Q5); here the adjoint of the forward map x -> conv(x): the stride-1
+            # convolution of the zero-dilated del_y with the flipped kernels.  Against the oracle composite and by <conv(x'), del_y> == <x', del_x>.
+            dxx = dev.empty((cin, h, w)).fill_bytes(0xFF); scratch = dev.empty((cout * cin * k * k,))
+            call(dev, "bla_conv2d_backward_f32", dev.to_device(del_y), dx_, dk_, dkern, dxx, scratch, h, w, k, cin, cout, s)
+            assert (np.abs(dkern.numpy() - want) <= 1e-5 * b1).all()
+            dcol64 = dq @ fw["kmat"].T; b2 = (np.abs(dq) @ np.abs(fw["kmat"]).T).max() * k * k
+            assert (np.abs(dxx.numpy() - ora.col2im_adjoint(dcol64, cin, h, w, k, s)) <= 1e-5 * b2).all(), cfg
+            xp = uniform(seed + 7, (cin, h, w), -1, 1, F32)
+            outp = dev.empty((cout, ho, wo)); call(dev, "bla_conv2d_forward_f32", dev.to_device(xp), dk_, outp, h, w, k, cin, cout, s)
+            lhs = float((outp.numpy().astype(np.float64) * del_y).sum()); rhs = float((xp.astype(np.float64) * dxx.numpy()).sum())
+            assert abs(lhs - rhs) <= 1e-5 * float((np.abs(outp.numpy()).astype(np.float64) * np.abs(del_y)).sum() + np.abs(xp * dxx.numpy()).sum())
+
+
+def test_strict_reference_refuses_undefined_strides():
+    """BLA_STRICT_REFERENCE=1 (read once per process): _col2im / conv_ddx / the implicit data gradient at stride != 1 answer
+    BLA_ERR_UNDEFINED (5) instead of the intended adjoint -- the reference indexes out of bounds there (lib/conv.c:80-135)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from __graft_entry__ import load_pkg\n"
+            "d = load_pkg(); d.init(0); L = d.lib(); z = d.zeros((4096,))\n"
+            "r = [L.bla_col2im_f32(None, z.ptr, z.ptr, 8, 8, 3, 2, 2), L.bla_conv_backward_f32(None, *([z.ptr] * 9), 8, 8, 3, 2, 2, 2),\n"
+            "     L.bla_conv2d_backward_f32(None, z.ptr, z.ptr, z.ptr, None, z.ptr, z.ptr, 8, 8, 3, 2, 2, 2), L.bla_col2im_f32(None, z.ptr, z.ptr, 8, 8, 3, 2, 1)]\n"
+            "print(r)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BLA_STRICT_REFERENCE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "[5, 5, 5, 0]", r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("batch", [2, 5, 33])
