@@ -51,3 +51,35 @@ void bla_host_down(float* h, const float* d, size_t floats) {
 	if (floats) BLA_TRY(bla_memcpy_d2h(h, d, floats * sizeof(float), NULL));
 	BLA_TRY(bla_stream_sync(NULL));
 }
+
+static float* g_pack[2];
+static size_t g_pack_cap[2];
+
+float* bla_host_pack_block(int which, size_t floats) {
+	if (floats > g_pack_cap[which]) {
+		free(g_pack[which]);
+		g_pack_cap[which] = floats + floats / 4;
+		g_pack[which] = malloc(g_pack_cap[which] * sizeof(float));
+		if (!g_pack[which]) { fprintf(stderr, "big-linear-algebra (MI355X backend): out of host memory for a %zu-float staging block\n", floats); exit(1); }
+	}
+	return g_pack[which];
+}
+
+float* bla_host_up_planes(int slot, Matrix* ch, int count) {
+	const size_t per = (size_t)ch[0].rows * ch[0].cols;
+	int contiguous = 1;
+	for (int c = 1; c < count && contiguous; c++) contiguous = ch[c].data == ch[0].data + c * per;
+	if (contiguous) return bla_host_up(slot, ch[0].data, per * count);
+	float* block = bla_host_pack_block(0, per * count);
+	for (int c = 0; c < count; c++) memcpy(block + c * per, ch[c].data, per * sizeof(float));
+	float* d = bla_host_up(slot, block, per * count);
+	BLA_TRY(bla_stream_sync(NULL));       /* the block is reused by the next operand */
+	return d;
+}
+
+void bla_host_down_planes(Matrix* ch, int count, const float* d) {
+	const size_t per = (size_t)ch[0].rows * ch[0].cols;
+	float* block = bla_host_pack_block(1, per * count);
+	bla_host_down(block, d, per * count);
+	for (int c = 0; c < count; c++) memcpy(ch[c].data, block + c * per, per * sizeof(float));
+}

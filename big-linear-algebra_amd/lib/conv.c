@@ -19,38 +19,30 @@
 #include "bla_host.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 enum { S_X = 3, S_KERN, S_IM2COL, S_KMAT, S_PRODUCT, S_OUTPUT, S_AUX0, S_AUX1, S_AUX2 };
 
-/* stage an array of `count` equally sized matrices into one contiguous device buffer */
-static float* up_channels(int slot, Matrix* ch, int count) {
-	size_t per = (size_t)ch[0].rows * ch[0].cols;
-	float* d = bla_host_buf(slot, per * count);
-	for (int c = 0; c < count; c++) BLA_TRY(bla_memcpy_h2d(d + c * per, ch[c].data, per * sizeof(float), NULL));
-	return d;
-}
-
-static void down_channels(Matrix* ch, int count, const float* d) {
-	size_t per = (size_t)ch[0].rows * ch[0].cols;
-	for (int c = 0; c < count; c++) BLA_TRY(bla_memcpy_d2h(ch[c].data, d + c * per, per * sizeof(float), NULL));
-	BLA_TRY(bla_stream_sync(NULL));
-}
+/* channel arrays travel as one copy per operand (bla_host_up_planes / bla_host_down_planes); kernel sets [F][C] likewise */
+#define up_channels bla_host_up_planes
+#define down_channels bla_host_down_planes
 
 static float* up_kernels(int slot, Matrix** kernels, int f_n, int c_n) {
-	size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
-	float* d = bla_host_buf(slot, per * c_n * f_n);
+	const size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
+	float* block = bla_host_pack_block(0, per * c_n * f_n);
 	for (int f = 0; f < f_n; f++)
-		for (int c = 0; c < c_n; c++)
-			BLA_TRY(bla_memcpy_h2d(d + ((size_t)f * c_n + c) * per, kernels[f][c].data, per * sizeof(float), NULL));
+		for (int c = 0; c < c_n; c++) memcpy(block + ((size_t)f * c_n + c) * per, kernels[f][c].data, per * sizeof(float));
+	float* d = bla_host_up(slot, block, per * c_n * f_n);
+	BLA_TRY(bla_stream_sync(NULL));
 	return d;
 }
 
 static void down_kernels(Matrix** kernels, int f_n, int c_n, const float* d) {
-	size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
+	const size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
+	float* block = bla_host_pack_block(1, per * c_n * f_n);
+	bla_host_down(block, d, per * c_n * f_n);
 	for (int f = 0; f < f_n; f++)
-		for (int c = 0; c < c_n; c++)
-			BLA_TRY(bla_memcpy_d2h(kernels[f][c].data, d + ((size_t)f * c_n + c) * per, per * sizeof(float), NULL));
-	BLA_TRY(bla_stream_sync(NULL));
+		for (int c = 0; c < c_n; c++) memcpy(kernels[f][c].data, block + ((size_t)f * c_n + c) * per, per * sizeof(float));
 }
 
 /* reference lib/conv.c:8-77 */

@@ -3,18 +3,9 @@
 #include "norm.h"
 #include "bla_host.h"
 
-static float* gather(int slot, Matrix* ch, int channels) {
-	size_t per = (size_t)ch[0].rows * ch[0].cols;
-	float* d = bla_host_buf(slot, per * channels);
-	for (int c = 0; c < channels; c++) BLA_TRY(bla_memcpy_h2d(d + c * per, ch[c].data, per * sizeof(float), NULL));
-	return d;
-}
-
-static void scatter(Matrix* ch, int channels, const float* d) {
-	size_t per = (size_t)ch[0].rows * ch[0].cols;
-	for (int c = 0; c < channels; c++) BLA_TRY(bla_memcpy_d2h(ch[c].data, d + c * per, per * sizeof(float), NULL));
-	BLA_TRY(bla_stream_sync(NULL));
-}
+/* one copy per channel array (bla_host_up_planes packs the per-channel Matrix planes first) */
+#define gather bla_host_up_planes
+#define scatter bla_host_down_planes
 
 void group_norm(Matrix* in, Matrix* out, matrix_float_t* stdevs, matrix_float_t* means, int channels, int group_size) {
 	int hw = in[0].rows * in[0].cols, groups = (channels + group_size - 1) / group_size;
