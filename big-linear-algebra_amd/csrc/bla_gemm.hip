@@ -586,24 +586,41 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//    standing in a clump behind the barrier.  All LDS reads of a phase come before its first DMA: hipcc waits for vmcnt(0) in
 	//    front of any LDS read that follows an LDS-DMA.
 	// the half-slab interleaved pipeline: always for 4x4 blocks per wave (256x256, 128x512), on request (HS) for 2x2 (128x128)
-	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && (TM == 2 || TM == 4) && (TN == 2 || TN == 4))) && (KK == 2 || KK == 4) && GATHER == 0 && !PERSIST && NBUF == 2;
+	// (the padded-copy convolution modes 3 / 4 run on it too: their gather is one more address per DMA instruction, dealt out between MFMAs like the rest)
+	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && (TM == 2 || TM == 4) && (TN == 2 || TN == 4))) && (KK == 2 || KK == 4) &&
+	                          (GATHER == 0 || ((GATHER == 3 || GATHER == 4) && HS)) && !PERSIST && NBUF == 2;
 	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
 #if defined(__HIP_DEVICE_COMPILE__)
-	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab (dense operands); the offsets advance in dma_advance()
+	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab; the offsets / gather cursors advance in dma_advance()
 		float* base = lds + buf * (A_SZ + B_SZ);
 		if (d < A_NI) {
 			const int i = d;
-			if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
+			if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy)
+				const float* src = p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[i] + p.g_ktab[g_r + g4_chunk[i]].x);
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+			} else if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + g_adv_a), (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 		} else {
 			const int i = d - A_NI;
-			if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
+			if (GATHER == 3) {   // gathered operand: four consecutive output pixels = four consecutive floats of the padded copy, tap from the scalar table
+				const int idx = wave * B_NI + i, kr = idx * 2 + (lane >> 5);
+				const float* src = p.g_img + (g3_base + p.g_ktab[g_k + kr].x);
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + idx * 256), 16, 0, 0);
+			} else if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb[i] + g_adv_b), (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
 		}
 	};
 	auto dma_advance = [&](bool really) {   // uniform select, no branch: past the last slab the cursor stays on it (harmless re-fetch)
 		const int sa = really ? (int)(a_step * 4) : 0, sb = really ? (int)(b_step * 4) : 0;
+		if (GATHER == 3) { soff_a += sa; g_k += really ? BK : 0; return; }
+		if (GATHER == 4) {   // B = del_y [image][N][HWo]: the pixel cursor wraps into the next image (HWo % 16 == 0: a slab never straddles two)
+			const int r1 = g_r + (really ? BK : 0);
+			const bool wrap = r1 >= p.g_HWo;
+			soff_b += (really ? BK * 4 : 0) + (wrap ? (p.N - 1) * p.g_HWo * 4 : 0);
+			g_r = wrap ? 0 : r1; g_img += wrap ? 1 : 0;
+			return;
+		}
 		if (A_BUF) soff_a += sa; else g_adv_a += really ? a_step : 0;
 		if (B_BUF) soff_b += sb; else g_adv_b += really ? b_step : 0;
 	};
@@ -645,6 +662,20 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 								make_float4(acc[im][in][4 * qq], acc[im][in][4 * qq + 1], acc[im][in][4 * qq + 2], acc[im][in][4 * qq + 3]);
 					}
 			}
+			return;
+		}
+		if constexpr (GATHER == 3 && HALFSLAB) {   // whole tiles; a lane owns TN consecutive columns (the row-contiguous operand's interleaved blocks)
+#pragma unroll
+			for (int im = 0; im < TM; im++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+					const int col = n0 + wn0 + TN * l31;              // TN consecutive pixels of one image (HWo % 4 == 0)
+					const int b = col / p.g_HWo, rr = col - b * p.g_HWo;
+					float* cp = p.C + (size_t)b * p.M * p.g_HWo + (size_t)row * p.g_HWo + rr;
+					if (TN == 4) *reinterpret_cast<float4*>(cp) = make_float4(acc[im][0][r], acc[im][1][r], acc[im][TN > 2 ? 2 : 0][r], acc[im][TN > 3 ? 3 : 0][r]);
+					else *reinterpret_cast<float2*>(cp) = make_float2(acc[im][0][r], acc[im][1][r]);
+				}
 			return;
 		}
 		if (GATHER == 1 || GATHER == 3) {   // C is [image][M][HWo]: column n = (image, pixel)
@@ -1445,7 +1476,12 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	}
 	dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits), block(256);
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
-	if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
+	// whole tiles: the half-slab pipeline (fragment sets per k-half, every LDS read and DMA dealt out between MFMAs) -- BLA_CONV_HS=0 keeps the older form
+	static const bool use_hs = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '0'); }();
+	const bool hs = use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || mode == 4);
+	if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
+	else if (hs) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true>), grid, block, lds_bytes, s, a);
+	else if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
 	else if (mode == 2) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 2>), grid, block, lds_bytes, s, a);
 	else if (mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3>), grid, block, lds_bytes, s, a);
 	else hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4>), grid, block, lds_bytes, s, a);
