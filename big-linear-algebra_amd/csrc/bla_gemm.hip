@@ -592,20 +592,41 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
 #if defined(__HIP_DEVICE_COMPILE__)
+	// Gather tables of the half-slab pipeline: the entries a slab's DMA instructions need are wave-uniform (tap rows of mode 3, the four
+	// pixel chunks of mode 4), so they are SCALAR loads, issued when the cursor moves -- a whole slab before the DMA that uses them.  (A per-lane
+	// table load in front of each DMA waits on vmcnt, i.e. for every LDS-DMA issued before it: 256->256 @16x16 ran 11 % slower that way.)
+	int hs_tap[B_NI][2], hs_pix[4] = {0, 0, 0, 0};
+	auto hs_prefetch = [&]() {
+		if (GATHER == 3) {
+#pragma unroll
+			for (int i = 0; i < B_NI; i++) {
+				const int row = __builtin_amdgcn_readfirstlane(g_k + (wave * B_NI + i) * 2);
+				hs_tap[i][0] = p.g_ktab[row].x; hs_tap[i][1] = p.g_ktab[row + 1].x;
+			}
+		}
+		if (GATHER == 4) {
+			const int r = __builtin_amdgcn_readfirstlane(g_r);
+#pragma unroll
+			for (int c = 0; c < 4; c++) hs_pix[c] = p.g_ktab[r + 4 * c].x;
+		}
+	};
+	if (HALFSLAB && (GATHER == 3 || GATHER == 4)) hs_prefetch();
 	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab; the offsets / gather cursors advance in dma_advance()
 		float* base = lds + buf * (A_SZ + B_SZ);
 		if (d < A_NI) {
 			const int i = d;
 			if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy)
-				const float* src = p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[i] + p.g_ktab[g_r + g4_chunk[i]].x);
+				const int c = g4_chunk[i] >> 2;     // which of the slab's four pixel chunks this lane fetches: its offset was loaded a slab ahead (hs_pix)
+				const int pix = c == 0 ? hs_pix[0] : c == 1 ? hs_pix[1] : c == 2 ? hs_pix[2] : hs_pix[3];
+				const float* src = p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[i] + pix);
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 			} else if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + g_adv_a), (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 		} else {
 			const int i = d - A_NI;
 			if (GATHER == 3) {   // gathered operand: four consecutive output pixels = four consecutive floats of the padded copy, tap from the scalar table
-				const int idx = wave * B_NI + i, kr = idx * 2 + (lane >> 5);
-				const float* src = p.g_img + (g3_base + p.g_ktab[g_k + kr].x);
+				const int idx = wave * B_NI + i;   // the instruction covers k-rows 2 idx (lanes 0-31) and 2 idx + 1: their tap offsets were loaded a slab ahead (hs_tap)
+				const float* src = p.g_img + (g3_base + ((lane >> 5) ? hs_tap[i][1] : hs_tap[i][0]));
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + idx * 256), 16, 0, 0);
 			} else if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb[i] + g_adv_b), (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
@@ -613,12 +634,13 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	};
 	auto dma_advance = [&](bool really) {   // uniform select, no branch: past the last slab the cursor stays on it (harmless re-fetch)
 		const int sa = really ? (int)(a_step * 4) : 0, sb = really ? (int)(b_step * 4) : 0;
-		if (GATHER == 3) { soff_a += sa; g_k += really ? BK : 0; return; }
+		if (GATHER == 3) { soff_a += sa; g_k += really ? BK : 0; hs_prefetch(); return; }
 		if (GATHER == 4) {   // B = del_y [image][N][HWo]: the pixel cursor wraps into the next image (HWo % 16 == 0: a slab never straddles two)
 			const int r1 = g_r + (really ? BK : 0);
 			const bool wrap = r1 >= p.g_HWo;
 			soff_b += (really ? BK * 4 : 0) + (wrap ? (p.N - 1) * p.g_HWo * 4 : 0);
 			g_r = wrap ? 0 : r1; g_img += wrap ? 1 : 0;
+			hs_prefetch();
 			return;
 		}
 		if (A_BUF) soff_a += sa; else g_adv_a += really ? a_step : 0;
