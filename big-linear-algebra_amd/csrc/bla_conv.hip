@@ -720,7 +720,7 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		if (MODE == CONV_WGRAD && fits32 && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w && a.N % 4 == 0) {
 			// stride 1: transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
-			const size_t slab_bytes = (size_t)gather_gemm_splits(4, batch, a.N, a.M) * a.M * a.N * sizeof(float);
+			const size_t slab_bytes = (size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float);
 			void* ws;
 			st = ensure_workspace(slab_bytes + (size_t)planes * hp * wp * sizeof(float) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;

@@ -1461,15 +1461,31 @@ static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, b
 #undef BLA_W
 }
 
-int gather_gemm_splits(int mode, int batch, int M, int N) {
-	if (mode != 2 && mode != 4) return 1;
+// K splits of a gathered weight-gradient product (contraction over (image, pixel), K = batch * HWo, few output tiles).  The tiles are MFMA-bound
+// and equally long, so what matters is that every CU gets the SAME number of workgroups: tiles * splits is rounded DOWN to a whole number of
+// workgroups per CU (one on the half-slab kernel, which holds one workgroup per CU; two on the older form) -- 9 tiles x 32 splits on 256 CUs
+// left 32 CUs with two workgroups and took twice the time of 9 x 28.  A split is a whole number of 16-deep slabs, not of images.
+static bool gather_hs(int mode, int M, int N) {
+	static const bool use_hs = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '0'); }();
+	return use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || mode == 4);
+}
+static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
+	const long K = (long)batch * HWo;
+	if (mode != 2 && mode != 4) return (int)K;
 	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
-	long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-	long want = (2L * cus + tiles - 1) / tiles;   // contraction over (image, pixel): whole images per split, ~2 workgroups per CU
-	int splits = (int)(want < batch ? want : batch);
+	const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+	const long slots = (gather_hs(mode, M, N) ? 1L : 2L) * cus;
+	long splits = slots / tiles;
+	const long slabs = K / 16;
+	if (splits > slabs / 8) splits = slabs / 8;      // at least 8 slabs per split
 	if (splits < 1) splits = 1;
-	int ips = (batch + splits - 1) / splits;      // images per split
-	return (batch + ips - 1) / ips;
+	return (int)((slabs + splits - 1) / splits) * 16;
+}
+int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
+	if (mode != 2 && mode != 4) return 1;
+	const long K = (long)batch * HWo;
+	const int kps = gather_k_per_split(mode, batch, M, N, HWo);
+	return (int)((K + kps - 1) / kps);
 }
 
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
@@ -1487,8 +1503,8 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
 	a.g_img = img; a.g_zero = zero_word(); a.g_ktab = ktab; a.g_ntab = ntab; a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
 	a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
-	const int splits = gather_gemm_splits(mode, batch, M, N);
-	a.k_per_split = (mode == 2 || mode == 4) ? (batch + splits - 1) / splits * HWo : K;
+	const int splits = gather_gemm_splits(mode, batch, M, N, HWo);
+	a.k_per_split = (mode == 2 || mode == 4) ? gather_k_per_split(mode, batch, M, N, HWo) : K;
 	a.splits = splits; a.slab = nullptr;
 	if (splits > 1) {
 		void* ws;
@@ -1499,8 +1515,7 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits), block(256);
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
 	// whole tiles: the half-slab pipeline (fragment sets per k-half, every LDS read and DMA dealt out between MFMAs) -- BLA_CONV_HS=0 keeps the older form
-	static const bool use_hs = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '0'); }();
-	const bool hs = use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || mode == 4);
+	const bool hs = gather_hs(mode, M, N);
 	if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
 	else if (hs) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true>), grid, block, lds_bytes, s, a);
 	else if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
