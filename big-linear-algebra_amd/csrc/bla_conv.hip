@@ -611,24 +611,38 @@ static bla_status get_pixel_table(hipStream_t s, const ConvGeom& g, const int2**
 	return BLA_OK;
 }
 
-// ---- stride-1 forward on a zero-padded copy ------------------------------------------------------------------------
-// dst [B*C][H+k-1][W+k-1] = src [B*C][H][W] surrounded by the SAME padding; one pass (33 MB for 64 x 128 x 32 x 32), after which
-// the gather needs no bounds checks and four consecutive output pixels of a row are four consecutive floats.  (The 16-byte DMAs
-// are mostly unaligned -- tap column q shifts the address by q floats and the pitch W+k-1 is even but rarely a multiple of 4;
-// forcing them aligned in an experiment changed nothing: 230.9 vs 229.9 us.)
-__global__ void __launch_bounds__(256) pad_image_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h, int w, int pt, int pl, int hp, int wp) {
-	size_t total = (size_t)planes * hp * wp;
-	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-		int x = (int)(e % wp) - pl; size_t t = e / wp;
-		int y = (int)(t % hp) - pt; size_t pc = t / hp;
+// ---- tiled gather on a zero-padded, stride-split copy -------------------------------------------------------------------------
+// One pass rewrites the batch as dst [B*C][s][s][Hh][Wh]: the image with its SAME padding, cut into its s x s parity planes
+// (dst[c][py][px][yy][xx] = padded[c][yy*s + py][xx*s + px], Hp = (Ho-1)s + k rows, Hh = ceil(Hp / s); 33 MB -> 38 MB for 64 x 128 x 32 x 32 at
+// stride 1, where there is one plane and this is plain padding).  After it the gather needs no bounds checks, and tap (p, q) of output pixels
+// (i, j .. j+3) is four CONSECUTIVE floats -- plane (p % s, q % s), row i + p / s, columns j + q / s .. -- for any stride, so the slab is
+// fetched with the same 16-byte DMA as a dense row-contiguous operand.  (The 16-byte DMAs are mostly unaligned; forcing them aligned in an
+// experiment changed nothing: 230.9 vs 229.9 us.)  32-bit index arithmetic: the copy is limited to 2 GiB anyway.
+__global__ void __launch_bounds__(256) pad_split_kernel(const float* __restrict__ src, float* __restrict__ dst, unsigned planes, int h, int w, int pt, int pl, int s,
+                                                        unsigned hh, unsigned wh) {
+	const unsigned total = planes * s * s * hh * wh;
+	for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		unsigned xx = e % wh, t = e / wh;
+		unsigned yy = t % hh; t /= hh;
+		unsigned px = t % s; t /= s;
+		unsigned py = t % s, pc = t / s;
+		const int y = (int)(yy * s + py) - pt, x = (int)(xx * s + px) - pl;
 		dst[e] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? src[(pc * h + y) * w + x] : 0.f;
 	}
 }
-__global__ void __launch_bounds__(256) padded_tables_kernel(int2* taps, int2* pix, int c_n, int k, int hp, int wp, int ho, int wo) {
+__global__ void __launch_bounds__(256) padded_tables_kernel(int2* taps, int2* pix, int c_n, int k, int s, int hh, int wh, int ho, int wo) {
 	int e = blockIdx.x * blockDim.x + threadIdx.x;
 	int kk = k * k;
-	if (e < c_n * kk) { int c = e / kk, p = (e % kk) / k, q = e % k; taps[e] = make_int2(c * hp * wp + p * wp + q, 0); }
-	if (e < ho * wo) { int i = e / wo, j = e - i * wo; pix[e] = make_int2(i * wp + j, 0); }
+	if (e < c_n * kk) { int c = e / kk, p = (e % kk) / k, q = e % k; taps[e] = make_int2(((c * s + p % s) * s + q % s) * hh * wh + (p / s) * wh + q / s, 0); }
+	if (e < ho * wo) { int i = e / wo, j = e - i * wo; pix[e] = make_int2(i * wh + j, 0); }
+}
+struct PaddedGeom { int hh, wh; size_t plane_floats; };   // plane_floats: one channel's s*s*Hh*Wh
+static PaddedGeom padded_geom(const ConvGeom& g) {
+	const int hp = (g.ho - 1) * g.s + g.k, wp = (g.wo - 1) * g.s + g.k;
+	PaddedGeom pg;
+	pg.hh = (hp + g.s - 1) / g.s; pg.wh = (wp + g.s - 1) / g.s;
+	pg.plane_floats = (size_t)g.s * g.s * pg.hh * pg.wh;
+	return pg;
 }
 struct PaddedTables { int device; ConvGeom g; int2* taps; int2* pix; };
 static std::vector<PaddedTables> g_padded;
@@ -638,16 +652,17 @@ static bla_status get_padded_tables(hipStream_t s, const ConvGeom& g, const int2
 	const int dev = ctx().device;
 	for (const PaddedTables& e : g_padded) {
 		const ConvGeom& t = e.g;
-		if (e.device == dev && t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c) { *taps = e.taps; *pix = e.pix; return BLA_OK; }
+		if (e.device == dev && t.k == g.k && t.c == g.c && t.s == g.s && t.ho == g.ho && t.wo == g.wo) { *taps = e.taps; *pix = e.pix; return BLA_OK; }
 	}
 	bla_status st = table_build_allowed(s);
 	if (st) return st;
+	const PaddedGeom pg = padded_geom(g);
 	int nt = g.c * g.k * g.k, np = g.ho * g.wo;
 	int2 *t, *q;
 	BLA_HIP(hipMalloc((void**)&t, (size_t)nt * sizeof(int2)));
 	BLA_HIP(hipMalloc((void**)&q, (size_t)np * sizeof(int2)));
 	int n = nt > np ? nt : np;
-	hipLaunchKernelGGL(padded_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx().stream, t, q, g.c, g.k, g.h + g.k - 1, g.w + g.k - 1, g.ho, g.wo);
+	hipLaunchKernelGGL(padded_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx().stream, t, q, g.c, g.k, g.s, pg.hh, pg.wh, g.ho, g.wo);
 	BLA_HIP(hipGetLastError());
 	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	g_padded.push_back(PaddedTables{dev, g, t, q});
@@ -701,36 +716,38 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		bla_status st = get_pixel_table(s, a.g, &ptab);
 		if (st) return st;
 		// (the padded-copy kernels address the copy with 32-bit byte offsets: at most 2 GiB of it, and of del_y)
-		const bool fits32 = (long)batch * a.g.c * (a.g.h + a.g.k - 1) * (a.g.w + a.g.k - 1) < (1L << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
-		if (MODE == CONV_FWD && fits32 && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w) {
-			// stride 1: pad once, then the B slab is fetched with the same 16-byte DMA as a dense operand
-			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
+		const PaddedGeom pg = padded_geom(a.g);
+		const size_t copy_floats = (size_t)batch * a.g.c * pg.plane_floats;
+		const bool fits32 = copy_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
+		if (MODE == CONV_FWD && fits32 && a.g.wo % 4 == 0) {
+			// pad (and split by stride parity) once, then the B slab is fetched with the same 16-byte DMA as a dense operand
 			void* ws;
-			st = ensure_workspace((size_t)planes * hp * wp * sizeof(float) + 64, &ws);
+			st = ensure_workspace(copy_floats * sizeof(float) + 64, &ws);
 			if (st) return st;
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
-			hipLaunchKernelGGL(pad_image_kernel, dim3(grid_for((size_t)planes * hp * wp)), dim3(256), 0, s, a.img, (float*)ws, planes, a.g.h, a.g.w, a.g.pt, a.g.pl, hp, wp);
+			hipLaunchKernelGGL(pad_split_kernel, dim3(grid_for(copy_floats)), dim3(256), 0, s, a.img, (float*)ws, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl,
+			                   a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
 			BLA_HIP(hipGetLastError());
-			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, (const float*)ws, taps, pix, hp, wp, a.N, a.g.c * hp * wp);
+			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, (const float*)ws, taps, pix, pg.hh, pg.wh, a.N, (int)(a.g.c * pg.plane_floats));
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
-		if (MODE == CONV_WGRAD && fits32 && a.g.s == 1 && a.g.wo % 4 == 0 && a.g.ho == a.g.h && a.g.wo == a.g.w && a.N % 4 == 0) {
-			// stride 1: transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
-			const int hp = a.g.h + a.g.k - 1, wp = a.g.w + a.g.k - 1, planes = batch * a.g.c;
+		if (MODE == CONV_WGRAD && fits32 && a.g.wo % 4 == 0 && a.N % 4 == 0) {
+			// transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const size_t slab_bytes = (size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float);
 			void* ws;
-			st = ensure_workspace(slab_bytes + (size_t)planes * hp * wp * sizeof(float) + 64, &ws);   // [slabs][padded copy]
+			st = ensure_workspace(slab_bytes + copy_floats * sizeof(float) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;
 			float* padded = (float*)((char*)ws + slab_bytes);
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
-			hipLaunchKernelGGL(pad_image_kernel, dim3(grid_for((size_t)planes * hp * wp)), dim3(256), 0, s, a.img, padded, planes, a.g.h, a.g.w, a.g.pt, a.g.pl, hp, wp);
+			hipLaunchKernelGGL(pad_split_kernel, dim3(grid_for(copy_floats)), dim3(256), 0, s, a.img, padded, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl,
+			                   a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
 			BLA_HIP(hipGetLastError());
-			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, hp, wp, a.K, a.g.c * hp * wp);
+			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, pg.hh, pg.wh, a.K, (int)(a.g.c * pg.plane_floats));
 		}
 		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
 		return gather_gemm(s, 2, batch, a.M, a.N, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, ptab, a.tab, a.g.h, a.g.w, a.K, (int)img_stride);

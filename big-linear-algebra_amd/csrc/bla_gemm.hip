@@ -1467,7 +1467,10 @@ static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, b
 // left 32 CUs with two workgroups and took twice the time of 9 x 28.  A split is a whole number of 16-deep slabs, not of images.
 static bool gather_hs(int mode, int M, int N) {
 	static const bool use_hs = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '0'); }();
-	return use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || mode == 4);
+	// mode 3 (forward / data gradient): the half-slab form (172 vs 198 us at 128->128 @32x32 x64); mode 4 (weight gradient) measured slower on it
+	// (208 vs 191 us: its one workgroup per CU against two of the older form), BLA_CONV_HS=2 forces it there too
+	static const bool hs4 = [] { const char* e = getenv("BLA_CONV_HS"); return e && e[0] == '2'; }();
+	return use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || (mode == 4 && hs4));
 }
 static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
 	const long K = (long)batch * HWo;

@@ -253,11 +253,14 @@ def test_batched_conv_equals_per_image_calls(dev, ora, batch):
         assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk).all(), ci
 
 
-@pytest.mark.parametrize("shape", [(64, 16, 16, 16, 64, 3, 1), (256, 16, 16, 16, 64, 3, 2), (120, 12, 12, 16, 72, 3, 1), (40, 20, 20, 32, 128, 1, 1)])
+@pytest.mark.parametrize("shape", [(64, 16, 16, 16, 64, 3, 1), (256, 16, 16, 16, 64, 3, 2), (120, 12, 12, 16, 72, 3, 1), (40, 20, 20, 32, 128, 1, 1),
+                                   (128, 32, 32, 16, 128, 3, 2), (64, 32, 32, 16, 128, 3, 1), (96, 14, 18, 16, 128, 3, 2)])
 def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
     """Batches big enough to fill the chip with 128x128 tiles run on the LDS-tiled gather kernel (direct-to-LDS 4-byte loads from
-    computed addresses, zero padding from a zero word): forward, data gradient and batch-summed weight gradient against the
-    oracle's per-image conv()/conv_ddx(), GEMM tolerance 1e-5 * (|A||B|); ragged M / N tiles, stride 2, 1x1 kernels."""
+    computed addresses, zero padding from a zero word; or, when the output rows are multiples of four pixels, 16-byte loads from the
+    zero-padded, stride-split copy -- on the half-slab pipeline for whole 128-row tiles): forward, data gradient (stride 2: the adjoint, via
+    the zero-dilated del_y) and batch-summed weight gradient against the oracle's per-image conv()/conv_ddx(), GEMM tolerance
+    1e-5 * (|A||B|); ragged M / N tiles, stride 2, 1x1 kernels, odd-sized maps."""
     batch, h, w, cin, cout, k, s = shape
     ho, wo = ora.out_hw(h, w, s)
     x = uniform(810, (batch, cin, h, w), -1, 1, F32); kern = uniform(811, (cout, cin, k, k), -0.3, 0.3, F32)
@@ -266,10 +269,10 @@ def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
     out = dev.empty((batch, cout, ho, wo)).fill_bytes(0xFF)
     call(dev, "bla_conv2d_forward_batched_f32", dx_, dk_, out, batch, h, w, k, cin, cout, s)
     dkern = dev.empty((cout, cin, k, k)).fill_bytes(0xFF)
-    dxx = dev.empty((batch, cin, h, w)).fill_bytes(0xFF) if s == 1 else None
-    scratch = dev.empty((cout * cin * k * k,)) if s == 1 else None
+    dxx = dev.empty((batch, cin, h, w)).fill_bytes(0xFF)
+    scratch = dev.empty((cout * cin * k * k,))
     call(dev, "bla_conv2d_backward_batched_f32", dy_, dx_, dk_, dkern, dxx, scratch, batch, h, w, k, cin, cout, s)
-    got, got_dx = out.numpy(), (dxx.numpy() if s == 1 else None)
+    got, got_dx = out.numpy(), dxx.numpy()
     want_dk = np.zeros((cout, cin, k, k)); bound_dk = np.zeros((cout, cin, k, k))
     kmat_abs = None
     for b in range(0, batch, max(1, batch // 16)):          # every 16th image in full detail, all images for the weight gradient below
@@ -280,6 +283,10 @@ def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
             dd = ora.conv_ddx_intended(del_y[b].astype(np.float64), fw["im2col"], fw["kmat"], cin, k)
             b2 = (np.abs(dd["del_q"]) @ np.abs(fw["kmat"]).T).max() * k * k
             assert (np.abs(got_dx[b] - dd["del_x"]) <= 1e-5 * b2).all(), (shape, b)
+        else:   # the intended data gradient: adjoint of _im2col applied to del_Q . kernel_matrix^T
+            dq = ora.reshape_matrix_channels(del_y[b].astype(np.float64))
+            b2 = (np.abs(dq) @ np.abs(fw["kmat"]).T).max() * k * k
+            assert (np.abs(got_dx[b] - ora.col2im_adjoint(dq @ fw["kmat"].T, cin, h, w, k, s)) <= 1e-5 * b2).all(), (shape, b)
     # weight gradient: sum over all images, im2col via numpy strides would be long-winded -- use the oracle per image
     for b in range(batch):
         cols = ora.im2col(x[b].astype(np.float64), k, s)                                   # [HoWo][K]
