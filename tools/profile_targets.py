@@ -26,12 +26,12 @@ if target.startswith("conv"):
     dy = bla.to_device(uniform(33, (B, cout, ho, ho), -1, 1, np.float32))
     out, dk, dx, scr = bla.empty((B, cout, ho, ho)), bla.empty((cout, cin, k, k)), bla.empty((B, cin, h, h)), bla.empty((cout * kkc,))
     fl = 2.0 * hw * kkc * cout * B
-    info.update(flops_forward=fl, flops_backward=2 * fl if s == 1 else fl,
+    info.update(flops_forward=fl, flops_backward=2 * fl,
                 bytes_forward=4.0 * (B * cin * h * h + cout * kkc + B * cout * hw),                       # input + kernels + output (not the im2col)
-                bytes_backward=4.0 * (B * cout * hw + B * cin * h * h + cout * kkc + cout * kkc + (B * cin * h * h if s == 1 else 0)))
+                bytes_backward=4.0 * (B * cout * hw + B * cin * h * h + cout * kkc + cout * kkc + B * cin * h * h))
     def run():
         chk(L.bla_conv2d_forward_batched_f32(st, x.ptr, kern.ptr, out.ptr, B, h, h, k, cin, cout, s))
-        chk(L.bla_conv2d_backward_batched_f32(st, dy.ptr, x.ptr, kern.ptr, dk.ptr, dx.ptr if s == 1 else None, scr.ptr, B, h, h, k, cin, cout, s))
+        chk(L.bla_conv2d_backward_batched_f32(st, dy.ptr, x.ptr, kern.ptr, dk.ptr, dx.ptr, scr.ptr, B, h, h, k, cin, cout, s))
 elif target in ("mnist", "mnist_dp"):
     mn = bla.mnist_nn
     nn = mn.MnistNN(256, colsum_mode=mn.COLSUM_INTENDED)
