@@ -1,0 +1,410 @@
+// bla_unet_model.hip -- the reference's U-Net (model/cifar_unet.c) assembled from the device-resident blocks of bla_unet.hip:
+// forward() (:1099-1166) and backward() (:1351-1436) for one image, parameters and gradients in two flat buckets.
+//
+//   18 ResNet blocks (8 down, 2 mid, 8 up), 5 self-attention blocks (two at resolution 2 on the way down, one in the middle, two at
+//   resolution 2 on the way up), 3 stride-2 down-convolutions, 3 nearest-neighbour up-samplings (each followed by a channel-changing
+//   convolution only where the two resolutions' widths differ, :1131,1141,1151), 4 skip concatenations, output group-norm + ReLU + conv.
+//
+// The reference's own model is work in progress: its backward pass walks out of bounds, and several call sites hand the
+// wrong buffers around.  This composition is the INTENDED network, block for block what the reference's functions compute when they are
+// wired as their comments and the forward pass say:
+//   * the second attention block of the third up-sampling stage has its own parameters and reads the second ResNet block's result
+//     (as written :1150 calls the first block's parameters again and :1151 then reads an output nobody wrote);
+//   * the data gradient of the three stride-2 convolutions is the stride-2 adjoint (as written :1412,1420,1430 pass stride 1 and _col2im
+//     indexes out of bounds);
+//   * a skip connection's gradient is ADDED to the gradient that arrives along the main path (as written :1424-1427 adds it first and
+//     then lets _backward_attention overwrite the sum);
+//   * convolution gradients land in the gradient bucket (as written :1203,1216 hand conv_ddx the parameters as the sink).
+// Every block is pinned on its own against the reference's functions (tests/test_resnet.py, test_attention.py, test_conv_gpu.py,
+// test_unet_glue.py); the composition is pinned against the same composition of the oracle's blocks (tests/test_unet_model.py).
+#include "bla_internal.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace bla;
+
+namespace {
+struct Tensor { size_t off, count; std::string name; };
+struct Res {
+	int cin, cout, h, w;
+	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
+	bla_resnet_ws ws;
+	float* result;
+	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
+};
+struct Att {
+	int c, h, w;
+	size_t wq, wk, wv, wo, bias;
+	bla_attention_ws fwd;
+	float* out;
+};
+struct Conv {
+	int cin, cout, h, w, stride, k;       // h, w: INPUT size
+	size_t kern;
+	float* out;
+	bool present;
+};
+constexpr size_t kNone = (size_t)-1;
+}  // namespace
+
+struct bla_unet {
+	bla_unet_config cfg;
+	int H[4], W[4];
+	std::vector<Tensor> tensors;
+	size_t count = 0, drop_count = 0;
+	float *params = nullptr, *grads = nullptr;
+	Res res[18];
+	Att att[5];
+	Conv down[3], up[3], outc;
+	float *cat[4] = {nullptr, nullptr, nullptr, nullptr};      // skip concatenations, stage order up_1 .. up_4
+	float *nn[3] = {nullptr, nullptr, nullptr};                // nearest-neighbour outputs
+	float *out_relu = nullptr, *out_mu = nullptr, *out_sd = nullptr;
+	unsigned char* zero_drop = nullptr;
+	// backward
+	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
+	bla_resnet_scratch sc = {};
+	bla_attention_ws agrad = {};
+	const float* last_x = nullptr; const float* last_temb = nullptr; const unsigned char* last_drop = nullptr;
+	std::vector<void*> owned;
+};
+
+namespace {
+bla_status dalloc(bla_unet* m, float** p, size_t floats) {
+	void* q = nullptr;
+	BLA_HIP(hipMalloc(&q, (floats ? floats : 1) * sizeof(float)));
+	m->owned.push_back(q);
+	*p = (float*)q;
+	return BLA_OK;
+}
+size_t add_tensor(bla_unet* m, const std::string& name, size_t count) {
+	size_t off = m->count;
+	m->tensors.push_back(Tensor{off, count, name});
+	m->count += (count + 3) / 4 * 4;    // every tensor 16-byte aligned inside the bucket
+	return off;
+}
+void plan_res(bla_unet* m, Res& r, const std::string& name, int cin, int cout, int h, int w) {
+	const int k = m->cfg.kernel, t = m->cfg.time_dim;
+	r.cin = cin; r.cout = cout; r.h = h; r.w = w;
+	r.conv1 = add_tensor(m, name + ".conv_1_kernels", (size_t)cout * cin * k * k);
+	r.conv2 = add_tensor(m, name + ".conv_2_kernels", (size_t)cout * cout * k * k);
+	r.tw = add_tensor(m, name + ".time_weights", (size_t)t * cout);
+	r.tb = add_tensor(m, name + ".time_biases", (size_t)cout);
+	r.res = cin != cout ? add_tensor(m, name + ".residual_conv_kernels", (size_t)cout * cin) : kNone;
+	r.drop_off = m->drop_count;
+	m->drop_count += (size_t)cout * h * w;
+}
+void plan_att(bla_unet* m, Att& a, const std::string& name, int c, int h, int w) {
+	const int d = m->cfg.key_dim;
+	a.c = c; a.h = h; a.w = w;
+	a.wq = add_tensor(m, name + ".Q_proj", (size_t)c * d);
+	a.wk = add_tensor(m, name + ".K_proj", (size_t)c * d);
+	a.wv = add_tensor(m, name + ".V_proj", (size_t)c * d);
+	a.wo = add_tensor(m, name + ".weights", (size_t)d * c);
+	a.bias = add_tensor(m, name + ".biases", (size_t)c);
+}
+void plan_conv(bla_unet* m, Conv& c, const std::string& name, int cin, int cout, int h, int w, int stride, bool present = true) {
+	c.cin = cin; c.cout = cout; c.h = h; c.w = w; c.stride = stride; c.k = m->cfg.kernel; c.present = present; c.out = nullptr;
+	c.kern = present ? add_tensor(m, name, (size_t)cout * cin * c.k * c.k) : kNone;
+}
+bla_status alloc_res(bla_unet* m, Res& r) {
+	const size_t hw = (size_t)r.h * r.w;
+	const int gs = m->cfg.group_size, g1 = (r.cin + gs - 1) / gs, g2 = (r.cout + gs - 1) / gs;
+	bla_status st;
+	if ((st = dalloc(m, &r.ws.mu1, g1)) || (st = dalloc(m, &r.ws.sd1, g1)) || (st = dalloc(m, &r.ws.relu1, r.cin * hw)) || (st = dalloc(m, &r.ws.c1, r.cout * hw)) ||
+	    (st = dalloc(m, &r.ws.tdense, r.cout)) || (st = dalloc(m, &r.ws.mu2, g2)) || (st = dalloc(m, &r.ws.sd2, g2)) || (st = dalloc(m, &r.ws.relu2, r.cout * hw)) ||
+	    (st = dalloc(m, &r.ws.dp, r.cout * hw)) || (st = dalloc(m, &r.ws.c2, r.cout * hw)) || (st = dalloc(m, &r.result, r.cout * hw)))
+		return st;
+	r.ws.res = nullptr;
+	if (r.cin != r.cout) st = dalloc(m, &r.ws.res, r.cout * hw);
+	return st;
+}
+bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s, size_t d) {
+	bla_status st;
+	if ((st = dalloc(m, &ws.q, s * d)) || (st = dalloc(m, &ws.k, s * d)) || (st = dalloc(m, &ws.v, s * d)) || (st = dalloc(m, &ws.attention, s * d)) ||
+	    (st = dalloc(m, &ws.scores_raw, s * s)) || (st = dalloc(m, &ws.weights, s * s)))
+		return st;
+	return BLA_OK;
+}
+
+// del_Y = 2 (prediction - noise), model/cifar_unet.c:1353-1364
+__global__ void __launch_bounds__(256) unet_loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ noise, float* __restrict__ g, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] = 2.f * (out[i] - noise[i]);
+}
+}  // namespace
+
+extern "C" {
+
+bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(out && cfg, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(cfg->image_h > 0 && cfg->image_w > 0 && cfg->in_channels > 0 && cfg->time_dim > 0 && cfg->kernel > 0 && cfg->group_size > 0 && cfg->key_dim > 0 &&
+	            cfg->dims[0] > 0 && cfg->dims[1] > 0 && cfg->dims[2] > 0 && cfg->dims[3] > 0, BLA_ERR_INVALID, "bad U-Net configuration");
+	BLA_REQUIRE(cfg->image_h % 8 == 0 && cfg->image_w % 8 == 0, BLA_ERR_INVALID, "image size must be a multiple of 8 (three halvings, each undone by a x2 up-sampling)");
+	bla_unet* m = new bla_unet();
+	m->cfg = *cfg;
+	const int* D = cfg->dims;
+	m->H[0] = cfg->image_h; m->W[0] = cfg->image_w;
+	for (int i = 1; i < 4; i++) { m->H[i] = (m->H[i - 1] + 1) / 2; m->W[i] = (m->W[i - 1] + 1) / 2; }   // RESOLUTION_n_HEIGHT, :39-46
+	const int* H = m->H; const int* W = m->W;
+	// parameter bucket, in the order of first use by forward()
+	plan_res(m, m->res[0], "down_1_resnet_1", cfg->in_channels, D[0], H[0], W[0]);
+	plan_res(m, m->res[1], "down_1_resnet_2", D[0], D[0], H[0], W[0]);
+	plan_conv(m, m->down[0], "down_1_conv_kernels", D[0], D[1], H[0], W[0], 2);
+	plan_res(m, m->res[2], "down_2_resnet_1", D[1], D[1], H[1], W[1]);
+	plan_att(m, m->att[0], "down_2_self_attention_1", D[1], H[1], W[1]);
+	plan_res(m, m->res[3], "down_2_resnet_2", D[1], D[1], H[1], W[1]);
+	plan_att(m, m->att[1], "down_2_self_attention_2", D[1], H[1], W[1]);
+	plan_conv(m, m->down[1], "down_2_conv_kernels", D[1], D[2], H[1], W[1], 2);
+	plan_res(m, m->res[4], "down_3_resnet_1", D[2], D[2], H[2], W[2]);
+	plan_res(m, m->res[5], "down_3_resnet_2", D[2], D[2], H[2], W[2]);
+	plan_conv(m, m->down[2], "down_3_conv_kernels", D[2], D[3], H[2], W[2], 2);
+	plan_res(m, m->res[6], "down_4_resnet_1", D[3], D[3], H[3], W[3]);
+	plan_res(m, m->res[7], "down_4_resnet_2", D[3], D[3], H[3], W[3]);
+	plan_res(m, m->res[8], "mid_resnet_1", D[3], D[3], H[3], W[3]);
+	plan_att(m, m->att[2], "mid_self_attention", D[3], H[3], W[3]);
+	plan_res(m, m->res[9], "mid_resnet_2", D[3], D[3], H[3], W[3]);
+	plan_res(m, m->res[10], "up_1_resnet_1", 2 * D[3], D[3], H[3], W[3]);
+	plan_res(m, m->res[11], "up_1_resnet_2", D[3], D[3], H[3], W[3]);
+	plan_conv(m, m->up[0], "up_1_conv_kernels", D[3], D[2], H[2], W[2], 1, D[3] != D[2]);
+	plan_res(m, m->res[12], "up_2_resnet_1", 2 * D[2], D[2], H[2], W[2]);
+	plan_res(m, m->res[13], "up_2_resnet_2", D[2], D[2], H[2], W[2]);
+	plan_conv(m, m->up[1], "up_2_conv_kernels", D[2], D[1], H[1], W[1], 1, D[2] != D[1]);
+	plan_res(m, m->res[14], "up_3_resnet_1", 2 * D[1], D[1], H[1], W[1]);
+	plan_att(m, m->att[3], "up_3_self_attention_1", D[1], H[1], W[1]);
+	plan_res(m, m->res[15], "up_3_resnet_2", D[1], D[1], H[1], W[1]);
+	plan_att(m, m->att[4], "up_3_self_attention_2", D[1], H[1], W[1]);
+	plan_conv(m, m->up[2], "up_3_conv_kernels", D[1], D[0], H[0], W[0], 1, D[1] != D[0]);
+	plan_res(m, m->res[16], "up_4_resnet_1", 2 * D[0], D[0], H[0], W[0]);
+	plan_res(m, m->res[17], "up_4_resnet_2", D[0], D[0], H[0], W[0]);
+	plan_conv(m, m->outc, "output_conv_kernels", D[0], cfg->in_channels, H[0], W[0], 1);
+
+	auto fail = [&](bla_status s) { (void)bla_unet_destroy(m); return s; };
+	if ((st = dalloc(m, &m->params, m->count)) || (st = dalloc(m, &m->grads, m->count))) return fail(st);
+	BLA_HIP(hipMemsetAsync(m->params, 0, m->count * sizeof(float), ctx().stream));
+	BLA_HIP(hipMemsetAsync(m->grads, 0, m->count * sizeof(float), ctx().stream));
+	size_t max_act = 0, max_s = 0, max_flip = 0, max_cout_hw = 0, max_cin_hw = 0;
+	for (Res& r : m->res) {
+		if ((st = alloc_res(m, r))) return fail(st);
+		const size_t hw = (size_t)r.h * r.w;
+		max_act = std::max(max_act, (size_t)std::max(r.cin, r.cout) * hw);
+		max_cout_hw = std::max(max_cout_hw, r.cout * hw); max_cin_hw = std::max(max_cin_hw, r.cin * hw);
+		max_flip = std::max(max_flip, (size_t)r.cout * std::max(r.cin, r.cout) * cfg->kernel * cfg->kernel);
+	}
+	for (Att& a : m->att) {
+		const size_t s = (size_t)a.h * a.w;
+		if ((st = alloc_att_ws(m, a.fwd, s, cfg->key_dim)) || (st = dalloc(m, &a.out, a.c * s))) return fail(st);
+		max_s = std::max(max_s, s);
+	}
+	for (int i = 0; i < 3; i++) {
+		Conv& c = m->down[i];
+		if ((st = dalloc(m, &c.out, (size_t)c.cout * H[i + 1] * W[i + 1]))) return fail(st);
+		max_flip = std::max(max_flip, (size_t)c.cout * c.cin * c.k * c.k);
+		Conv& u = m->up[i];
+		if ((st = dalloc(m, &m->nn[i], (size_t)u.cin * u.h * u.w))) return fail(st);
+		if (u.present) {
+			if ((st = dalloc(m, &u.out, (size_t)u.cout * u.h * u.w))) return fail(st);
+			max_flip = std::max(max_flip, (size_t)u.cout * u.cin * u.k * u.k);
+		}
+		max_act = std::max(max_act, (size_t)u.cin * u.h * u.w);
+	}
+	const int stage_dim[4] = {D[3], D[2], D[1], D[0]}, stage_res[4] = {3, 2, 1, 0};
+	for (int i = 0; i < 4; i++) {
+		const size_t n = (size_t)stage_dim[i] * H[stage_res[i]] * W[stage_res[i]];
+		if ((st = dalloc(m, &m->cat[i], 2 * n)) || (st = dalloc(m, &m->gskip[i], n))) return fail(st);
+		max_act = std::max(max_act, 2 * n);
+	}
+	const size_t hw0 = (size_t)H[0] * W[0];
+	const int g0 = (D[0] + cfg->group_size - 1) / cfg->group_size;
+	if ((st = dalloc(m, &m->outc.out, cfg->in_channels * hw0)) || (st = dalloc(m, &m->out_relu, D[0] * hw0)) || (st = dalloc(m, &m->out_mu, g0)) ||
+	    (st = dalloc(m, &m->out_sd, g0)))
+		return fail(st);
+	max_flip = std::max(max_flip, (size_t)cfg->in_channels * D[0] * cfg->kernel * cfg->kernel);
+	if ((st = dalloc(m, &m->t1, max_act)) || (st = dalloc(m, &m->t2, max_act)) || (st = dalloc(m, &m->t3, max_act)) || (st = dalloc(m, &m->sc.g_out_a, max_cout_hw)) ||
+	    (st = dalloc(m, &m->sc.g_out_b, max_cout_hw)) || (st = dalloc(m, &m->sc.g_in, max_cin_hw)) || (st = dalloc(m, &m->sc.flip, max_flip)) ||
+	    (st = alloc_att_ws(m, m->agrad, max_s, cfg->key_dim)))
+		return fail(st);
+	void* z = nullptr;
+	BLA_HIP(hipMalloc(&z, m->drop_count ? m->drop_count : 1));
+	m->owned.push_back(z);
+	m->zero_drop = (unsigned char*)z;
+	BLA_HIP(hipMemsetAsync(z, 0, m->drop_count ? m->drop_count : 1, ctx().stream));
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
+	*out = m;
+	return BLA_OK;
+}
+
+bla_status bla_unet_destroy(bla_unet* m) {
+	if (!m) return BLA_OK;
+	(void)hipDeviceSynchronize();
+	for (void* p : m->owned) (void)hipFree(p);
+	delete m;
+	return BLA_OK;
+}
+
+size_t bla_unet_param_count(const bla_unet* m) { return m ? m->count : 0; }
+float* bla_unet_params(bla_unet* m) { return m ? m->params : nullptr; }
+float* bla_unet_grads(bla_unet* m) { return m ? m->grads : nullptr; }
+float* bla_unet_output(bla_unet* m) { return m ? m->outc.out : nullptr; }
+size_t bla_unet_dropout_count(const bla_unet* m) { return m ? m->drop_count : 0; }
+int bla_unet_tensor_count(const bla_unet* m) { return m ? (int)m->tensors.size() : 0; }
+
+bla_status bla_unet_tensor_info(const bla_unet* m, int index, size_t* offset, size_t* count, char* name, int name_len) {
+	BLA_REQUIRE(m && index >= 0 && index < (int)m->tensors.size(), BLA_ERR_INVALID, "tensor index out of range");
+	const Tensor& t = m->tensors[index];
+	if (offset) *offset = t.off;
+	if (count) *count = t.count;
+	if (name && name_len > 0) { strncpy(name, t.name.c_str(), name_len - 1); name[name_len - 1] = '\0'; }
+	return BLA_OK;
+}
+
+/* forward(), model/cifar_unet.c:1099-1166 */
+bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, const float* d_time_embedding, const unsigned char* d_drop) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(m && d_x && d_time_embedding, BLA_ERR_INVALID, "null argument");
+	const bla_unet_config& c = m->cfg;
+	const int* D = c.dims; const int* H = m->H; const int* W = m->W;
+	const float* P = m->params;
+	m->last_x = d_x; m->last_temb = d_time_embedding; m->last_drop = d_drop;
+	auto res = [&](int i, const float* in) -> bla_status {
+		Res& r = m->res[i];
+		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
+		return bla_resnet_forward_f32(stream, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off, &r.ws, r.result, r.h, r.w, r.cin, r.cout,
+		                              c.kernel, c.time_dim, c.group_size);
+	};
+	auto att = [&](int i, const float* in) -> bla_status {
+		Att& a = m->att[i];
+		return bla_attention_forward_f32(stream, in, P + a.wq, P + a.wk, P + a.wv, P + a.wo, P + a.bias, &a.fwd, a.out, a.c, a.h * a.w, c.key_dim);
+	};
+	auto conv = [&](Conv& k, const float* in) -> bla_status {
+		return bla_conv2d_forward_f32(stream, in, P + k.kern, k.out, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+	};
+	auto concat = [&](int stage, const float* a, const float* skip, size_t n) -> bla_status {   // _concat_skip, :1088-1097
+		bla_status s2 = bla_memcpy_d2d(m->cat[stage], a, n * sizeof(float), stream);
+		return s2 ? s2 : bla_memcpy_d2d(m->cat[stage] + n, skip, n * sizeof(float), stream);
+	};
+	auto upsample = [&](int i, const float* in, const float** next) -> bla_status {   // _nearest_neighbours (+ the optional convolution), :1125-1131
+		Conv& u = m->up[i];
+		bla_status s2 = bla_nearest_neighbours_f32(stream, in, m->nn[i], u.cin, H[3 - i], W[3 - i], u.h, u.w, 2);
+		*next = m->nn[i];
+		if (!s2 && u.present) { s2 = conv(u, m->nn[i]); *next = u.out; }
+		return s2;
+	};
+#define TRY(x) do { st = (x); if (st) return st; } while (0)
+	// down
+	TRY(res(0, d_x)); TRY(res(1, m->res[0].result));
+	TRY(conv(m->down[0], m->res[1].result));
+	TRY(res(2, m->down[0].out)); TRY(att(0, m->res[2].result)); TRY(res(3, m->att[0].out)); TRY(att(1, m->res[3].result));
+	TRY(conv(m->down[1], m->att[1].out));
+	TRY(res(4, m->down[1].out)); TRY(res(5, m->res[4].result));
+	TRY(conv(m->down[2], m->res[5].result));
+	TRY(res(6, m->down[2].out)); TRY(res(7, m->res[6].result));
+	// mid
+	TRY(res(8, m->res[7].result)); TRY(att(2, m->res[8].result)); TRY(res(9, m->att[2].out));
+	// up
+	const float* next;
+	TRY(concat(0, m->res[9].result, m->res[7].result, (size_t)D[3] * H[3] * W[3]));
+	TRY(res(10, m->cat[0])); TRY(res(11, m->res[10].result));
+	TRY(upsample(0, m->res[11].result, &next));
+	TRY(concat(1, next, m->res[5].result, (size_t)D[2] * H[2] * W[2]));
+	TRY(res(12, m->cat[1])); TRY(res(13, m->res[12].result));
+	TRY(upsample(1, m->res[13].result, &next));
+	TRY(concat(2, next, m->res[3].result, (size_t)D[1] * H[1] * W[1]));
+	TRY(res(14, m->cat[2])); TRY(att(3, m->res[14].result)); TRY(res(15, m->att[3].out)); TRY(att(4, m->res[15].result));
+	TRY(upsample(2, m->att[4].out, &next));
+	TRY(concat(3, next, m->res[1].result, (size_t)D[0] * H[0] * W[0]));
+	TRY(res(16, m->cat[3])); TRY(res(17, m->res[16].result));
+	// output, :1163-1165
+	TRY(bla_group_norm_relu_f32(stream, m->res[17].result, m->out_relu, m->out_sd, m->out_mu, D[0], c.group_size, H[0] * W[0]));
+	TRY(conv(m->outc, m->out_relu));
+	return BLA_OK;
+}
+
+/* backward(), model/cifar_unet.c:1351-1436 (intended wiring, see the head of this file): fills the gradient bucket for the image, time
+ * embedding and dropout decisions of the last forward pass. */
+bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise) {
+	bla_status st = require_ready();
+	if (st) return st;
+	BLA_REQUIRE(m && d_noise, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(m->last_x, BLA_ERR_INVALID, "bla_unet_forward_f32 has not run");
+	const bla_unet_config& c = m->cfg;
+	const int* D = c.dims; const int* H = m->H; const int* W = m->W;
+	const float* P = m->params; float* G = m->grads;
+	const float* temb = m->last_temb;
+	hipStream_t s = pick_stream(stream);
+	// ResNet block i: gradient `g` of its result -> `out` (gradient of its input `x`)
+	auto res = [&](int i, const float* g, const float* x, float* out) -> bla_status {
+		Res& r = m->res[i];
+		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
+		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
+		return bla_resnet_backward_f32(stream, g, x, temb, &p, &r.ws, &gr, &m->sc, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim, c.group_size);
+	};
+	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
+		Att& a = m->att[i];
+		return bla_attention_backward_f32(stream, g, x, P + a.wq, P + a.wk, P + a.wv, P + a.wo, &a.fwd, &m->agrad, G + a.wq, G + a.wk, G + a.wv, G + a.wo, out, a.c,
+		                                  a.h * a.w, c.key_dim, 0);
+	};
+	auto conv = [&](Conv& k, const float* g, const float* x, float* out) -> bla_status {
+		return bla_conv2d_backward_f32(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+	};
+	// up-sampling stage i backwards: gradient of (the optional convolution's output | the resized map) -> gradient of the map before resizing;
+	// g, tmp and out are three different buffers
+	auto upsample = [&](int i, const float* g, float* tmp, float* out) -> bla_status {
+		Conv& u = m->up[i];
+		const float* gn = g;
+		if (u.present) { bla_status s2 = conv(u, g, m->nn[i], tmp); if (s2) return s2; gn = tmp; }
+		return bla_nearest_neighbours_ddx_f32(stream, gn, out, u.cin, u.h, u.w, H[3 - i], W[3 - i], 2);
+	};
+	auto keep_skip = [&](int stage, const float* g_cat, size_t n) -> bla_status {   // _split_concat, :1339-1349: the second half is the skip's gradient
+		return bla_memcpy_d2d(m->gskip[stage], g_cat + n, n * sizeof(float), stream);
+	};
+	// three rotating gradient buffers: a block never writes the buffer it reads
+	float *a = m->t1, *b = m->t2, *cbuf = m->t3;
+	const size_t hw0 = (size_t)H[0] * W[0];
+	const size_t n0 = (size_t)D[0] * hw0, n1 = (size_t)D[1] * H[1] * W[1], n2 = (size_t)D[2] * H[2] * W[2], n3 = (size_t)D[3] * H[3] * W[3];
+	const int nout = (int)(c.in_channels * hw0);
+	hipLaunchKernelGGL(unet_loss_grad_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, m->outc.out, d_noise, a, nout);   // :1353-1364
+	BLA_HIP(hipGetLastError());
+	// output processing, :1367-1369: convolution, ReLU gate, group norm
+	TRY(conv(m->outc, a, m->out_relu, b));
+	TRY(group_norm_ddx_gated(stream, b, a, m->res[17].result, m->out_mu, m->out_sd, D[0], c.group_size, (int)hw0, m->out_relu, nullptr));
+	// fourth up-sampling stage, :1372-1374
+	TRY(res(17, a, m->res[16].result, b)); TRY(res(16, b, m->cat[3], a));
+	TRY(keep_skip(3, a, n0));
+	// third, :1377-1383 (resize and the optional convolution, then attention 2, ResNet 2, attention 1, ResNet 1)
+	TRY(upsample(2, a, b, cbuf));
+	TRY(att(4, cbuf, m->res[15].result, a)); TRY(res(15, a, m->att[3].out, b)); TRY(att(3, b, m->res[14].result, a)); TRY(res(14, a, m->cat[2], b));
+	TRY(keep_skip(2, b, n1));
+	// second, :1386-1390
+	TRY(upsample(1, b, a, cbuf));
+	TRY(res(13, cbuf, m->res[12].result, a)); TRY(res(12, a, m->cat[1], b));
+	TRY(keep_skip(1, b, n2));
+	// first, :1393-1397
+	TRY(upsample(0, b, a, cbuf));
+	TRY(res(11, cbuf, m->res[10].result, a)); TRY(res(10, a, m->cat[0], b));
+	TRY(keep_skip(0, b, n3));
+	// middle, :1400-1402
+	TRY(res(9, b, m->att[2].out, a)); TRY(att(2, a, m->res[8].result, b)); TRY(res(8, b, m->res[7].result, a));
+	// fourth down-sampling stage, :1405-1409: the skip's gradient joins the main path's
+	TRY(bla_add_f32(stream, a, m->gskip[0], n3));
+	TRY(res(7, a, m->res[6].result, b)); TRY(res(6, b, m->down[2].out, a));
+	// third, :1412-1417
+	TRY(conv(m->down[2], a, m->res[5].result, b));
+	TRY(bla_add_f32(stream, b, m->gskip[1], n2));
+	TRY(res(5, b, m->res[4].result, a)); TRY(res(4, a, m->down[1].out, b));
+	// second, :1420-1427
+	TRY(conv(m->down[1], b, m->att[1].out, a));
+	TRY(att(1, a, m->res[3].result, b));
+	TRY(bla_add_f32(stream, b, m->gskip[2], n1));
+	TRY(res(3, b, m->att[0].out, a)); TRY(att(0, a, m->res[2].result, b)); TRY(res(2, b, m->down[0].out, a));
+	// first, :1430-1435
+	TRY(conv(m->down[0], a, m->res[1].result, b));
+	TRY(bla_add_f32(stream, b, m->gskip[3], n0));
+	TRY(res(1, b, m->res[0].result, a)); TRY(res(0, a, m->last_x, b));
+	return BLA_OK;
+}
+#undef TRY
+
+}  // extern "C"

@@ -290,6 +290,31 @@ BLA_API bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out,
                                            const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
                                            int cin, int cout, int k, int tdim, int group_size);
 
+/* ---- the U-Net of model/cifar_unet.c assembled from the blocks above: forward() (:1099-1166) and backward() (:1351-1436) for one image.
+ * 18 ResNet blocks, 5 self-attention blocks, 3 stride-2 convolutions, 3 nearest-neighbour up-samplings (+ a convolution where the widths of the
+ * two resolutions differ), 4 skip concatenations, output group norm + ReLU + convolution.  Parameters and gradients live in two flat buckets;
+ * bla_unet_tensor_info enumerates the tensors (names follow the reference's struct members, e.g. "down_2_resnet_1.conv_1_kernels",
+ * "mid_self_attention.Q_proj", "up_3_conv_kernels") in the order forward() first uses them.  The wiring is the INTENDED network: see
+ * csrc/bla_unet_model.hip for the four places where the reference's work-in-progress call sites differ.
+ * Reference constants (:26-37): image 32 x 32 x 3, dims {128, 256, 256, 256}, time_dim 512, kernel 3, group_size 32, key_dim 16. */
+typedef struct bla_unet_config { int image_h, image_w, in_channels, dims[4], time_dim, kernel, group_size, key_dim; } bla_unet_config;
+typedef struct bla_unet bla_unet;
+BLA_API bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg);
+BLA_API bla_status bla_unet_destroy(bla_unet* m);
+BLA_API size_t bla_unet_param_count(const bla_unet* m);         /* floats in each bucket (every tensor starts 16-byte aligned) */
+BLA_API float* bla_unet_params(bla_unet* m);                    /* device */
+BLA_API float* bla_unet_grads(bla_unet* m);                     /* device; written by bla_unet_backward_f32 */
+BLA_API float* bla_unet_output(bla_unet* m);                    /* device, [in_channels][H][W]: the predicted noise */
+BLA_API int bla_unet_tensor_count(const bla_unet* m);
+BLA_API bla_status bla_unet_tensor_info(const bla_unet* m, int index, size_t* offset, size_t* count, char* name, int name_len);
+/* _dropout (:1032-1042) draws one decision per element of every ResNet block's second ReLU, in forward order: d_drop holds
+ * bla_unet_dropout_count() of them (non-zero = dropped; the host makes the draws from its own rand() stream), NULL = keep everything. */
+BLA_API size_t bla_unet_dropout_count(const bla_unet* m);
+BLA_API bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x /* [C][H][W] */, const float* d_time_embedding /* [time_dim] */,
+                                        const unsigned char* d_drop);
+/* del_Y = 2 (prediction - noise) (:1353-1364), then every block backwards; uses the activations of the last forward pass */
+BLA_API bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise /* [C][H][W] */);
+
 /* ---- device-resident MNIST-NN trainer: the hot loop of model/mnist_nn.c:218-315 with everything in HBM -------
  * sizes = {n0, n1, n2, n3} (784, 256, 128, 10 in the reference, model/mnist_nn.c:25-28); samples are columns.
  * Parameters sit in one flat bucket ordered W1,b1,W2,b2,W3,b3 (each row-major), gradients in a second bucket of

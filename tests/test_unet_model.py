@@ -1,0 +1,124 @@
+"""The U-Net of model/cifar_unet.c assembled on the device (bla_unet_*: forward() :1099-1166, backward() :1351-1436, intended wiring)
+against the same composition of the oracle's blocks (oracle.unet: every block there is the restatement pinned to the reference's own
+functions).  A narrow configuration keeps the fp64 oracle to seconds: 16 x 16 image, widths 32 / 64 / 64 / 48 (so that one up-sampling stage
+has its channel-changing convolution and one does not), 3 input channels, dropout decisions from a fixed mask."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from inputs import uniform
+
+pytestmark = pytest.mark.gpu
+
+
+class Cfg(C.Structure):
+    _fields_ = [("image_h", C.c_int), ("image_w", C.c_int), ("in_channels", C.c_int), ("dims", C.c_int * 4), ("time_dim", C.c_int), ("kernel", C.c_int),
+                ("group_size", C.c_int), ("key_dim", C.c_int)]
+
+
+def tensor_shape(name, count, cfg):
+    k, t, d = cfg["kernel"], cfg["time_dim"], cfg["key_dim"]
+    if name.endswith("residual_conv_kernels"):
+        return None      # [cout][cin][1][1]: resolved below
+    return None
+
+
+def build(pkg, cfg):
+    L = pkg.lib(); chk = pkg.native.check
+    c = Cfg(cfg["image_h"], cfg["image_w"], cfg["in_channels"], (C.c_int * 4)(*cfg["dims"]), cfg["time_dim"], cfg["kernel"], cfg["group_size"], cfg["key_dim"])
+    h = C.c_void_p()
+    chk(L.bla_unet_create(C.byref(h), C.byref(c)))
+    tensors = []
+    for i in range(L.bla_unet_tensor_count(h)):
+        off, cnt = C.c_size_t(), C.c_size_t(); name = C.create_string_buffer(96)
+        chk(L.bla_unet_tensor_info(h, i, C.byref(off), C.byref(cnt), name, 96))
+        tensors.append((name.value.decode(), off.value, cnt.value))
+    return h, tensors
+
+
+def shapes_for(tensors, cfg):
+    """tensor name -> shape, from the layer widths the names imply"""
+    D, k, t, d, cin0 = cfg["dims"], cfg["kernel"], cfg["time_dim"], cfg["key_dim"], cfg["in_channels"]
+    width = {"down_1": D[0], "down_2": D[1], "down_3": D[2], "down_4": D[3], "mid": D[3], "up_1": D[3], "up_2": D[2], "up_3": D[1], "up_4": D[0]}
+    out = {}
+    for name, off, cnt in tensors:
+        stage = "mid" if name.startswith("mid") else name[:name.index("_", name.index("_") + 1)]
+        w = width.get(stage)
+        if name == "output_conv_kernels":
+            shp = (cin0, D[0], k, k)
+        elif name.endswith("_conv_kernels") and "resnet" not in name:           # down_n_conv_kernels / up_n_conv_kernels
+            n = int(name.split("_")[1])
+            shp = (D[n], D[n - 1], k, k) if name.startswith("down") else (D[3 - n], D[4 - n], k, k)
+        elif name.endswith(".conv_2_kernels"):
+            shp = (w, w, k, k)
+        elif name.endswith(".conv_1_kernels") or name.endswith(".residual_conv_kernels"):
+            kk = k if name.endswith(".conv_1_kernels") else 1
+            shp = (w, cnt // (w * kk * kk), kk, kk)
+        elif name.endswith(".time_weights"):
+            shp = (t, w)
+        elif name.endswith(".time_biases") or name.endswith(".biases"):
+            shp = (w,)
+        elif name.endswith(".weights"):
+            shp = (d, w)
+        else:                                                                   # Q_proj / K_proj / V_proj
+            shp = (w, d)
+        assert int(np.prod(shp)) == cnt, (name, shp, cnt)
+        out[name] = shp
+    return out
+
+
+def test_unet_forward_backward_against_oracle_composition(pkg, ora):
+    pkg.init(0)
+    L = pkg.lib(); chk = pkg.native.check
+    cfg = dict(image_h=16, image_w=16, in_channels=3, dims=[32, 64, 64, 48], time_dim=24, kernel=3, group_size=32, key_dim=8)
+    h, tensors = build(pkg, cfg)
+    names = [t[0] for t in tensors]
+    assert names[0] == "down_1_resnet_1.conv_1_kernels" and names[-1] == "output_conv_kernels"
+    assert "up_3_conv_kernels" in names and "up_1_conv_kernels" in names and "up_2_conv_kernels" not in names      # 64 -> 32, 48 -> 64; 64 == 64
+    assert "down_1_resnet_1.residual_conv_kernels" in names and "up_4_resnet_1.residual_conv_kernels" in names
+    shapes = shapes_for(tensors, cfg)
+    total = L.bla_unet_param_count(h)
+    flat = np.zeros(total, np.float32)
+    P = {}
+    for i, (name, off, cnt) in enumerate(tensors):
+        shp = shapes[name]
+        fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+        scale = 0.05 if name.endswith("biases") else float(np.sqrt(3.0 / fan_in))
+        v = uniform(7000 + i, shp, -scale, scale, np.float32)
+        flat[off:off + cnt] = v.ravel(); P[name] = v.astype(np.float64)
+    chk(L.bla_memcpy_h2d(L.bla_unet_params(h), flat.ctypes.data, flat.nbytes, None)); pkg.sync()
+    x = uniform(7901, (3, 16, 16), -1, 1, np.float32); temb = uniform(7902, (cfg["time_dim"],), -1, 1, np.float32)
+    noise = uniform(7903, (3, 16, 16), -1, 1, np.float32)
+    ndrop = L.bla_unet_dropout_count(h)
+    drop = (uniform(7904, (ndrop,), 0, 1, np.float32) < 0.1).astype(np.uint8)        # DROPOUT_RATE 0.1, :37
+    dx, dt, dn = pkg.to_device(x), pkg.to_device(temb), pkg.to_device(noise)
+    dd = pkg.DeviceArray((ndrop,), np.uint8).copy_from(drop)
+    chk(L.bla_unet_forward_f32(h, None, dx.ptr, dt.ptr, dd.ptr))
+    chk(L.bla_unet_backward_f32(h, None, dn.ptr))
+    pkg.sync()
+    out = np.empty((3, 16, 16), np.float32)
+    chk(L.bla_memcpy_d2h(out.ctypes.data, L.bla_unet_output(h), out.nbytes, None))
+    grads = np.empty(total, np.float32)
+    chk(L.bla_memcpy_d2h(grads.ctypes.data, L.bla_unet_grads(h), grads.nbytes, None)); pkg.sync()
+    want_out, G = ora.unet(cfg, P, x.astype(np.float64), temb.astype(np.float64), noise.astype(np.float64), drop)
+    assert np.isfinite(out).all() and np.abs(want_out).max() > 1e-3
+    err = np.linalg.norm(out - want_out) / np.linalg.norm(want_out)
+    assert err <= 1e-4, f"prediction: normwise error {err:.3e}"
+    worst = ("", 0.0)
+    for name, off, cnt in tensors:
+        g = grads[off:off + cnt].astype(np.float64); w = G[name].ravel()
+        scale = np.linalg.norm(w)
+        if scale == 0:
+            assert not g.any(), name
+            continue
+        e = np.linalg.norm(g - w) / scale
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e <= 2e-3, f"{name}: normwise gradient error {e:.3e}"
+    print(f"U-Net: prediction error {err:.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
+    # a second forward pass without dropout decisions (NULL = keep everything) differs from the first and is deterministic
+    chk(L.bla_unet_forward_f32(h, None, dx.ptr, dt.ptr, None)); pkg.sync()
+    out2 = np.empty_like(out); chk(L.bla_memcpy_d2h(out2.ctypes.data, L.bla_unet_output(h), out2.nbytes, None)); pkg.sync()
+    want2, _ = ora.unet(cfg, P, x.astype(np.float64), temb.astype(np.float64), noise.astype(np.float64), None)
+    assert np.linalg.norm(out2 - want2) / np.linalg.norm(want2) <= 1e-4 and np.abs(out2 - out).max() > 0
+    chk(L.bla_unet_destroy(h))
