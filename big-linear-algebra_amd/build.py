@@ -20,6 +20,7 @@ HOST = os.path.join(HERE, "lib")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIP_SO = os.path.join(CSRC, "libbla_hip.so")
 HOST_SO = os.path.join(HOST, "libbla_host.so")
+HOST_F64_SO = os.path.join(HOST, "libbla_host_f64.so")   # matrix.h in the reference's own element type (-DBLA_FP64)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -89,6 +90,10 @@ def build_host(force=False):
     hdrs = glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     if force or _newer(HOST_SO, srcs + hdrs + [HIP_SO]):
         _run(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-o", HOST_SO] + srcs +
+             ["-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}", "-lm"])
+    f64_srcs = [os.path.join(HOST, f) for f in ("matrix.c", "bla_host.c", "csv.c", "mnist_csv2.c")]
+    if force or _newer(HOST_F64_SO, f64_srcs + hdrs + [HIP_SO]):
+        _run(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-DBLA_FP64", "-I", INCLUDE, "-o", HOST_F64_SO] + f64_srcs +
              ["-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}", "-lm"])
     return HOST_SO
 

@@ -65,6 +65,7 @@ float* bla_host_pack_block(int which, size_t floats) {
 	return g_pack[which];
 }
 
+#ifndef BLA_FP64   /* the channel-array helpers serve conv.h / norm.h, which exist in fp32 only */
 float* bla_host_up_planes(int slot, Matrix* ch, int count) {
 	const size_t per = (size_t)ch[0].rows * ch[0].cols;
 	int contiguous = 1;
@@ -83,3 +84,4 @@ void bla_host_down_planes(Matrix* ch, int count, const float* d) {
 	bla_host_down(block, d, per * count);
 	for (int c = 0; c < count; c++) memcpy(ch[c].data, block + c * per, per * sizeof(float));
 }
+#endif

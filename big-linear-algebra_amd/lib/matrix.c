@@ -8,6 +8,27 @@
 #include <string.h>
 #include <math.h>
 
+/* Element type on the device = matrix_float_t: float by default, double under -DBLA_FP64 (the reference's own type, lib/matrix.h:4).  The
+ * staging buffers of bla_host.c are counted in floats: WORDS() converts. */
+#ifdef BLA_FP64
+typedef double dev_t;
+#define DEV(name) bla_##name##_f64
+#else
+typedef float dev_t;
+#define DEV(name) bla_##name##_f32
+#endif
+#define WORDS(n) ((size_t)(n) * (sizeof(matrix_float_t) / sizeof(float)))
+static dev_t* up(int slot, const matrix_float_t* h, size_t n) { return (dev_t*)bla_host_up(slot, (const float*)h, WORDS(n)); }
+static dev_t* buf(int slot, size_t n) { return (dev_t*)bla_host_buf(slot, WORDS(n)); }
+static void down(matrix_float_t* h, const dev_t* d, size_t n) { down((float*)h, (const float*)d, WORDS(n)); }
+static void dev_gemm(int m, int n, int k, const dev_t* a, const dev_t* b, dev_t* c) {
+#ifdef BLA_FP64
+	BLA_TRY(bla_gemm_f64(NULL, 0, 0, m, n, k, a, k, b, n, c, n, 1.0, 0.0));
+#else
+	BLA_TRY(bla_gemm_f32(NULL, 0, 0, m, n, k, a, k, b, n, c, n, NULL));
+#endif
+}
+
 /* reference lib/matrix.c:6-12: heap struct around caller-owned data */
 struct Matrix* make_matrix(int rows, int cols, matrix_float_t* data) {
 	struct Matrix* m = malloc(sizeof *m);
@@ -46,30 +67,30 @@ struct Matrix* matrix_multiply(struct Matrix a, struct Matrix b) {
 }
 
 /* reference lib/matrix.c:47-57: c = a @ b, no shape checks, c's own dims ignored (output stride is b->cols).
- * fp32 MFMA GEMM on the device. */
+ * MFMA GEMM on the device (fp32, or fp64 under -DBLA_FP64). */
 void matrix_multiply_inplace(Matrix* a, Matrix* b, Matrix* c) {
 	const int m = a->rows, k = a->cols, n = b->cols;
 	if (m <= 0 || n <= 0) return;
-	float* da = bla_host_up(0, a->data, (size_t)m * k);
-	float* db = bla_host_up(1, b->data, (size_t)k * n);
-	float* dc = bla_host_buf(2, (size_t)m * n);
-	BLA_TRY(bla_gemm_f32(NULL, 0, 0, m, n, k, da, k, db, n, dc, n, NULL));
-	bla_host_down(c->data, dc, (size_t)m * n);
+	dev_t* da = up(0, a->data, (size_t)m * k);
+	dev_t* db = up(1, b->data, (size_t)k * n);
+	dev_t* dc = buf(2, (size_t)m * n);
+	dev_gemm(m, n, k, da, db, dc);
+	down(c->data, dc, (size_t)m * n);
 }
 
 void matrix_scale(struct Matrix* m, matrix_float_t f) {          /* reference lib/matrix.c:59-63 */
 	size_t n = (size_t)m->rows * m->cols;
-	float* d = bla_host_up(0, m->data, n);
-	BLA_TRY(bla_scale_f32(NULL, d, n, f));
-	bla_host_down(m->data, d, n);
+	dev_t* d = up(0, m->data, n);
+	BLA_TRY(DEV(scale)(NULL, d, n, f));
+	down(m->data, d, n);
 }
 
 void matrix_add(struct Matrix* a, struct Matrix* b) {            /* reference lib/matrix.c:65-69: a's size is trusted */
 	size_t n = (size_t)a->rows * a->cols;
-	float* da = bla_host_up(0, a->data, n);
-	float* db = bla_host_up(1, b->data, n);
-	BLA_TRY(bla_add_f32(NULL, da, db, n));
-	bla_host_down(a->data, da, n);
+	dev_t* da = up(0, a->data, n);
+	dev_t* db = up(1, b->data, n);
+	BLA_TRY(DEV(add)(NULL, da, db, n));
+	down(a->data, da, n);
 }
 
 /* reference lib/matrix.c:71-89.  Note `< 0.01` also sends negative values to %.2e. */
@@ -93,20 +114,20 @@ void matrix_multiply_elementwise(struct Matrix* a, struct Matrix* b) {   /* refe
 		exit(1);
 	}
 	size_t n = (size_t)a->rows * a->cols;
-	float* da = bla_host_up(0, a->data, n);
-	float* db = bla_host_up(1, b->data, n);
-	BLA_TRY(bla_hadamard_f32(NULL, da, db, n));
-	bla_host_down(a->data, da, n);
+	dev_t* da = up(0, a->data, n);
+	dev_t* db = up(1, b->data, n);
+	BLA_TRY(DEV(hadamard)(NULL, da, db, n));
+	down(a->data, da, n);
 }
 
 /* reference lib/matrix.c:105-118: dims swapped in place, data rewritten (LDS-tiled transpose on the device) */
 void matrix_transpose(struct Matrix* m) {
 	const int r = m->rows, c = m->cols;
 	size_t n = (size_t)r * c;
-	float* din = bla_host_up(0, m->data, n);
-	float* dout = bla_host_buf(1, n);
-	BLA_TRY(bla_transpose_f32(NULL, din, dout, r, c));
-	bla_host_down(m->data, dout, n);
+	dev_t* din = up(0, m->data, n);
+	dev_t* dout = buf(1, n);
+	BLA_TRY(DEV(transpose)(NULL, din, dout, r, c));
+	down(m->data, dout, n);
 	m->rows = c;
 	m->cols = r;
 }
@@ -114,10 +135,10 @@ void matrix_transpose(struct Matrix* m) {
 struct Matrix* matrix_row_sum(struct Matrix m) {                  /* reference lib/matrix.c:123-133 -> 1 x cols */
 	matrix_float_t* data = malloc((size_t)m.cols * sizeof(matrix_float_t));
 	struct Matrix* out = make_matrix(1, m.cols, data);
-	float* d = bla_host_up(0, m.data, (size_t)m.rows * m.cols);
-	float* o = bla_host_buf(1, (size_t)m.cols);
-	BLA_TRY(bla_row_sum_f32(NULL, d, m.rows, m.cols, o));
-	bla_host_down(data, o, (size_t)m.cols);
+	dev_t* d = up(0, m.data, (size_t)m.rows * m.cols);
+	dev_t* o = buf(1, (size_t)m.cols);
+	BLA_TRY(DEV(row_sum)(NULL, d, m.rows, m.cols, o));
+	down(data, o, (size_t)m.cols);
 	return out;
 }
 
@@ -128,47 +149,47 @@ struct Matrix* matrix_row_sum(struct Matrix m) {                  /* reference l
 struct Matrix* matrix_col_sum(struct Matrix m) {
 	matrix_float_t* data = malloc((size_t)m.rows * sizeof(matrix_float_t));
 	struct Matrix* out = make_matrix(m.rows, 1, data);
-	float* d = bla_host_up(0, m.data, (size_t)m.rows * m.cols);
-	float* o = bla_host_buf(1, (size_t)m.rows);
+	dev_t* d = up(0, m.data, (size_t)m.rows * m.cols);
+	dev_t* o = buf(1, (size_t)m.rows);
 	int mode = m.rows <= m.cols ? BLA_COLSUM_AS_WRITTEN : BLA_COLSUM_INTENDED;
 	if (bla_host_strict()) mode = BLA_COLSUM_AS_WRITTEN;
-	BLA_TRY(bla_col_sum_f32(NULL, d, m.rows, m.cols, o, mode));
-	bla_host_down(data, o, (size_t)m.rows);
+	BLA_TRY(DEV(col_sum)(NULL, d, m.rows, m.cols, o, mode));
+	down(data, o, (size_t)m.rows);
 	return out;
 }
 
-static matrix_float_t reduce_scalar(struct Matrix m, bla_status (*fn)(void*, const float*, size_t, float*)) {
+static matrix_float_t reduce_scalar(struct Matrix m, bla_status (*fn)(void*, const dev_t*, size_t, dev_t*)) {
 	size_t n = (size_t)m.rows * m.cols;
-	float* d = bla_host_up(0, m.data, n);
-	float* o = bla_host_buf(1, 4);
+	dev_t* d = up(0, m.data, n);
+	dev_t* o = buf(1, 4);
 	BLA_TRY(fn(NULL, d, n, o));
-	float r;
-	bla_host_down(&r, o, 1);
+	matrix_float_t r;
+	down(&r, o, 1);
 	return r;
 }
 
-matrix_float_t frobenius_norm(struct Matrix m) { return reduce_scalar(m, bla_frobenius_f32); }   /* reference lib/matrix.c:150-158 */
-matrix_float_t max_value(struct Matrix m) { return reduce_scalar(m, bla_max_f32); }               /* reference lib/matrix.c:160-168 */
+matrix_float_t frobenius_norm(struct Matrix m) { return reduce_scalar(m, DEV(frobenius)); }   /* reference lib/matrix.c:150-158 */
+matrix_float_t max_value(struct Matrix m) { return reduce_scalar(m, DEV(max)); }               /* reference lib/matrix.c:160-168 */
 
 void matrix_z_score_normalize(Matrix* m) {                        /* reference lib/matrix.c:170-185 */
 	size_t n = (size_t)m->rows * m->cols;
-	float* d = bla_host_up(0, m->data, n);
-	BLA_TRY(bla_zscore_f32(NULL, d, n));
-	bla_host_down(m->data, d, n);
+	dev_t* d = up(0, m->data, n);
+	BLA_TRY(DEV(zscore)(NULL, d, n));
+	down(m->data, d, n);
 }
 
 void matrix_add_tile_columns(struct Matrix* a, struct Matrix* b) {   /* reference lib/matrix.c:189-195 */
 	size_t n = (size_t)a->rows * a->cols;
-	float* da = bla_host_up(0, a->data, n);
-	float* db = bla_host_up(1, b->data, (size_t)a->rows * b->cols);
-	BLA_TRY(bla_add_tile_columns_f32(NULL, da, a->rows, a->cols, db, b->cols));
-	bla_host_down(a->data, da, n);
+	dev_t* da = up(0, a->data, n);
+	dev_t* db = up(1, b->data, (size_t)a->rows * b->cols);
+	BLA_TRY(DEV(add_tile_columns)(NULL, da, a->rows, a->cols, db, b->cols));
+	down(a->data, da, n);
 }
 
 void matrix_add_tile_rows(struct Matrix* a, struct Matrix* b) {      /* reference lib/matrix.c:199-205 */
 	size_t n = (size_t)a->rows * a->cols;
-	float* da = bla_host_up(0, a->data, n);
-	float* db = bla_host_up(1, b->data, (size_t)a->cols);
-	BLA_TRY(bla_add_tile_rows_f32(NULL, da, a->rows, a->cols, db));
-	bla_host_down(a->data, da, n);
+	dev_t* da = up(0, a->data, n);
+	dev_t* db = up(1, b->data, (size_t)a->cols);
+	BLA_TRY(DEV(add_tile_rows)(NULL, da, a->rows, a->cols, db));
+	down(a->data, da, n);
 }

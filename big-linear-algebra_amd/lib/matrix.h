@@ -11,12 +11,18 @@
  * computes in fp32 on the device and therefore declares float (DESIGN.md "element type").  Every
  * reference program except the already-stale model/mnist.c compiles warning-free with float, and the
  * float typedef is what lib/layer.h's `void (*)(float*, int)` activation pointers actually require.
+ * Compiled with -DBLA_FP64 the type is double like the reference's and the functions of THIS header run in fp64 on the device (MFMA f64 GEMM;
+ * lib/libbla_host_f64.so) -- for comparing against the reference's CPU results to 1e-12; conv.h / norm.h / util.h / layer.h are fp32 only.
  *
  * Every call is host-coherent like the reference: operands are staged to HBM, the kernel runs, results
  * are copied back before the function returns; no pointer is retained across calls.  There is no CPU
  * compute path: without a gfx950 device the first call prints the error and exits with status 1.
  */
+#ifdef BLA_FP64
+typedef double matrix_float_t;   /* the reference's own element type (lib/matrix.h:4): the <= 1e-12 comparison build, matrix.h functions only */
+#else
 typedef float matrix_float_t;
+#endif
 
 /* Data is stored in row major order (reference lib/matrix.h:6-11) */
 typedef struct Matrix {

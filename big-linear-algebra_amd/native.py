@@ -71,6 +71,11 @@ SIGNATURES = {
     "bla_max_f32": (_I, [_VP, _VP, _SZ, _VP]), "bla_zscore_f32": (_I, [_VP, _VP, _SZ]),
     "bla_softmax_cols_f32": (_I, [_VP, _VP, _I, _I]), "bla_softmax_rows_f32": (_I, [_VP, _VP, _I, _I]),
     "bla_softmax_cols_grad_f32": (_I, [_VP, _VP, _I, _I, _VP, _F, _VP]),
+    "bla_gemm_f64": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, C.c_double, C.c_double]),
+    "bla_scale_f64": (_I, [_VP, _VP, _SZ, C.c_double]), "bla_add_f64": (_I, [_VP, _VP, _VP, _SZ]), "bla_hadamard_f64": (_I, [_VP, _VP, _VP, _SZ]),
+    "bla_add_tile_columns_f64": (_I, [_VP, _VP, _I, _I, _VP, _I]), "bla_add_tile_rows_f64": (_I, [_VP, _VP, _I, _I, _VP]),
+    "bla_transpose_f64": (_I, [_VP, _VP, _VP, _I, _I]), "bla_row_sum_f64": (_I, [_VP, _VP, _I, _I, _VP]), "bla_col_sum_f64": (_I, [_VP, _VP, _I, _I, _VP, _I]),
+    "bla_frobenius_f64": (_I, [_VP, _VP, _SZ, _VP]), "bla_max_f64": (_I, [_VP, _VP, _SZ, _VP]), "bla_zscore_f64": (_I, [_VP, _VP, _SZ]),
     "bla_conv_out_hw": (_I, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "bla_im2col_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]), "bla_col2im_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
     "bla_kernels_to_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]), "bla_matrix_to_kernels_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]),

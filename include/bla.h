@@ -196,6 +196,23 @@ BLA_API bla_status bla_softmax_rows_f32(void* stream, float* d, int rows, int co
 /* softmax per column, then d_grad = (softmax - y) * scale in the same pass (model/mnist_nn.c:234,263-268) */
 BLA_API bla_status bla_softmax_cols_grad_f32(void* stream, float* d, int rows, int cols, const float* d_y, float scale, float* d_grad);
 
+/* ---- the matrix.h path in the reference's own element type (lib/matrix.h:4: double) for the -DBLA_FP64 build of the host layer
+ * (SURVEY 7.0(1)): same meaning as the _f32 entries above, GEMM on v_mfma_f64_16x16x4_f64.  This is the <= 1e-12 comparison mode against the
+ * reference's CPU results (only the order of additions differs), not a performance path. */
+BLA_API bla_status bla_gemm_f64(void* stream, int transa, int transb, int m, int n, int k, const double* d_a, int lda, const double* d_b, int ldb,
+                                double* d_c, int ldc, double alpha, double beta);                             /* lib/matrix.c:35-57 */
+BLA_API bla_status bla_scale_f64(void* stream, double* d_m, size_t n, double f);                             /* :59-63 */
+BLA_API bla_status bla_add_f64(void* stream, double* d_a, const double* d_b, size_t n);                      /* :65-69 */
+BLA_API bla_status bla_hadamard_f64(void* stream, double* d_a, const double* d_b, size_t n);                 /* :95-103 */
+BLA_API bla_status bla_add_tile_columns_f64(void* stream, double* d_a, int a_rows, int a_cols, const double* d_b, int b_cols);   /* :189-195 */
+BLA_API bla_status bla_add_tile_rows_f64(void* stream, double* d_a, int a_rows, int a_cols, const double* d_b);                  /* :199-205 */
+BLA_API bla_status bla_transpose_f64(void* stream, const double* d_in, double* d_out, int rows, int cols);   /* :105-118 */
+BLA_API bla_status bla_row_sum_f64(void* stream, const double* d_m, int rows, int cols, double* d_out);      /* :123-133 */
+BLA_API bla_status bla_col_sum_f64(void* stream, const double* d_m, int rows, int cols, double* d_out, int mode);   /* :138-148 */
+BLA_API bla_status bla_frobenius_f64(void* stream, const double* d_m, size_t n, double* d_out);              /* :150-158 */
+BLA_API bla_status bla_max_f64(void* stream, const double* d_m, size_t n, double* d_out);                    /* :160-168 */
+BLA_API bla_status bla_zscore_f64(void* stream, double* d_m, size_t n);                                      /* :170-185 (sigma through sqrtf, as there) */
+
 /* ---- convolution stages, lib/conv.c.  Images are contiguous [C][H][W]; kernels [F][C][k][k]; workspaces are
  * the reference's ConvData members (lib/conv.h:6-11): im2col [Ho*Wo][k*k*C], kernel_matrix [k*k*C][F],
  * product [Ho*Wo][F], output [F][Ho][Wo].  TF "SAME" padding, Ho = ceil((float)H/stride) (lib/conv.c:13-28,55-56). */

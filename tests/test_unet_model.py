@@ -114,7 +114,7 @@ def test_unet_forward_backward_against_oracle_composition(pkg, ora):
             continue
         e = np.linalg.norm(g - w) / scale
         worst = max(worst, (name, e), key=lambda t: t[1])
-        assert e <= 2e-3, f"{name}: normwise gradient error {e:.3e}"
+        assert e <= 5e-4, f"{name}: normwise gradient error {e:.3e}"
     print(f"U-Net: prediction error {err:.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
     # a second forward pass without dropout decisions (NULL = keep everything) differs from the first and is deterministic
     chk(L.bla_unet_forward_f32(h, None, dx.ptr, dt.ptr, None)); pkg.sync()
