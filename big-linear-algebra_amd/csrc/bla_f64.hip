@@ -12,7 +12,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TB = 64, TK = 16;   // 64 x 64 output tile per 256-thread workgroup, 16-deep slabs
 
 // C[m x n] = alpha * op(A) . op(B) + beta * C.  Each of the four waves owns a 32 x 32 quarter = 2 x 2 blocks of 16 x 16;
-// v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15], holds D[4 (l >> 4) + r][l & 15], r = 0..3.
+// v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15], holds D[4 r + (l >> 4)][l & 15] in register r = 0..3.
 __global__ void __launch_bounds__(256) gemm_f64_kernel(int transa, int transb, int M, int N, int K, const double* __restrict__ A, int lda,
                                                         const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc, double alpha, double beta) {
 	__shared__ double As[TB][TK + 1];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(int transa, int transb, i
 		for (int j = 0; j < 2; j++)
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
-				const int row = m0 + wm + i * 16 + 4 * lq + r, col = n0 + wn + j * 16 + li;
+				const int row = m0 + wm + i * 16 + 4 * r + lq, col = n0 + wn + j * 16 + li;   // D register r of lane (li, lq) is row 4 r + lq
 				if (row < M && col < N) {
 					double* dst = C + (size_t)row * ldc + col;
 					*dst = beta != 0.0 ? alpha * acc[i][j][r] + beta * *dst : alpha * acc[i][j][r];

@@ -20,7 +20,7 @@ typedef float dev_t;
 #define WORDS(n) ((size_t)(n) * (sizeof(matrix_float_t) / sizeof(float)))
 static dev_t* up(int slot, const matrix_float_t* h, size_t n) { return (dev_t*)bla_host_up(slot, (const float*)h, WORDS(n)); }
 static dev_t* buf(int slot, size_t n) { return (dev_t*)bla_host_buf(slot, WORDS(n)); }
-static void down(matrix_float_t* h, const dev_t* d, size_t n) { down((float*)h, (const float*)d, WORDS(n)); }
+static void down(matrix_float_t* h, const dev_t* d, size_t n) { bla_host_down((float*)h, (const float*)d, WORDS(n)); }
 static void dev_gemm(int m, int n, int k, const dev_t* a, const dev_t* b, dev_t* c) {
 #ifdef BLA_FP64
 	BLA_TRY(bla_gemm_f64(NULL, 0, 0, m, n, k, a, k, b, n, c, n, 1.0, 0.0));
