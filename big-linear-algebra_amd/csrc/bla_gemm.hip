@@ -1352,6 +1352,17 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, Gemm
 	}
 }
 
+// Three independent products of the same layout class (A and B both K-contiguous: the three weight gradients dW_l = dZ_l . A_{l-1}^T of one
+// MNIST-NN step, model/mnist_nn.c:267-292) in ONE launch: workgroups [0, t1) run p, [t1, t2) run q, the rest r; each brings its own tile size.
+__global__ void __launch_bounds__(256) gemm_f32_wsk_triple_nt_kernel(GemmArgs p, GemmArgs q, GemmArgs r, int t1, int t2) {
+	__shared__ __attribute__((aligned(16))) WskShared sh;
+	const int b = (int)blockIdx.x;
+	const GemmArgs& a = b < t1 ? p : (b < t2 ? q : r);
+	const int bx = b < t1 ? b : (b < t2 ? b - t1 : b - t2);
+	if (a.wsk_tile == 16) wsk_body<16, true, true, true, true>(a, bx, 0, sh);
+	else wsk_body<32, true, true, true, true>(a, bx, 0, sh);
+}
+
 // Sums the split-K slabs in split order (deterministic) and applies the epilogue.
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
 	size_t total = (size_t)p.M * p.N;
@@ -1823,6 +1834,38 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk pair launch");
+	return BLA_OK;
+}
+
+/* Up to three INDEPENDENT products issued together (none reads what another writes).  Three latency-bound products whose operands are all
+ * K-contiguous (transa = 0, transb = 1) share ONE launch; two go through bla_gemm_pair_f32; anything else is issued one by one. */
+bla_status bla_gemm_group_f32(void* stream, const bla_gemm_desc* d, int count) {
+	BLA_REQUIRE(d && count >= 1 && count <= 3, BLA_ERR_INVALID, "1 to 3 descriptors");
+	if (count == 1) return gemm_impl(stream, d[0].transa, d[0].transb, d[0].m, d[0].n, d[0].k, d[0].A, d[0].lda, d[0].B, d[0].ldb, d[0].C, d[0].ldc, d[0].ep, nullptr);
+	if (count == 2) return bla_gemm_pair_f32(stream, &d[0], &d[1]);
+	WskPlan pl[3] = {};
+	const bool try_group = g_force_config < 0 && g_force_split <= 0;
+	bla_status st;
+	int planned = 0;
+	for (int i = 0; i < 3; i++) {
+		// a product that does not resolve to the un-split vectorised wave-split-K kernel launches right here (pl[i].valid stays false)
+		st = gemm_impl(stream, d[i].transa, d[i].transb, d[i].m, d[i].n, d[i].k, d[i].A, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].ldc, d[i].ep,
+		               try_group && !d[i].transa && d[i].transb ? &pl[i] : nullptr);
+		if (st) return st;
+		planned += pl[i].valid && !pl[i].a.softmax_grad ? 1 : 0;
+	}
+	hipStream_t s = pick_stream(stream);
+	hipError_t e = hipSuccess;
+	if (planned == 3) {
+		const int t1 = pl[0].a.tiles_m * pl[0].a.tiles_n, t2 = t1 + pl[1].a.tiles_m * pl[1].a.tiles_n, t3 = t2 + pl[2].a.tiles_m * pl[2].a.tiles_n;
+		hipLaunchKernelGGL(gemm_f32_wsk_triple_nt_kernel, dim3((unsigned)t3), dim3(256), 0, s, pl[0].a, pl[1].a, pl[2].a, t1, t2);
+		e = hipGetLastError();
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk_triple_nt_%dx%d+%dx%d+%dx%d", t1, pl[0].a.wsk_tile, t2 - t1, pl[1].a.wsk_tile, t3 - t2, pl[2].a.wsk_tile);
+	} else {
+		for (int i = 0; i < 3 && e == hipSuccess; i++)
+			if (pl[i].valid) e = launch_wsk(pl[i].a, pl[i].akc, pl[i].bkc, true, true, dim3((unsigned)(pl[i].a.tiles_m * pl[i].a.tiles_n), 1), s);
+	}
+	if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk group launch");
 	return BLA_OK;
 }
 

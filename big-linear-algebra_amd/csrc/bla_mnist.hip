@@ -42,6 +42,149 @@ struct bla_mnist_nn {
 
 using namespace bla;
 
+// ---- the per-sample chain of one step in ONE launch ---------------------------------------------------------------------------------
+// Everything between the first layer's activations and the first layer's pre-activation gradient is column-local -- sample k's column of
+// Z2, A2, Z3, A3, dZ3, dZ2 and dZ1 depends on no other sample (model/mnist_nn.c:226-234, 260-268, 273-278, 284-289); only the weight
+// gradients sum over columns.  As separate launches those five products cost ~5 us each of pure launch latency for < 1 us of MFMA work
+// (profiles/r02/mnist*).  Here one workgroup owns 16 columns and walks the whole chain with the intermediate columns in LDS:
+//     A1 cols -> Z2 = W2 A1 + b2, A2 = relu -> Z3 = W3 A2 + b3, A3 = softmax, dZ3 = (A3 - Y) / n0 [+ loss / accuracy] ->
+//     dZ2 = (W3^T dZ3) (.) relu'(Z2) -> dZ1 = (W2^T dZ2) (.) relu'(Z1)
+// on v_mfma_f32_16x16x4_f32 (lane l: index l & 15, k-slot l >> 4; a lane holds 4 consecutive k and MFMA j multiplies element j of every
+// lane, as in the wave-split-K GEMM).  A step is then three launches: the first layer's product, this chain, the three weight gradients.
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kChainMaxN1 = 256, kChainMaxN2 = 128;
+struct ChainArgs {
+	const float *A1, *Z1, *W2, *b2, *W3, *b3, *Y;
+	float *Z2, *A2, *Z3, *A3, *dZ3, *dZ2, *dZ1;
+	int n1, n2, n3, B, backward;
+	float gscale;
+	double* sm_loss; unsigned* sm_correct;
+};
+
+__global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
+	__shared__ __attribute__((aligned(16))) float a1c[16][kChainMaxN1 + 4];    // [column][k]: one ds_read_b128 = 4 consecutive k of a lane's column
+	__shared__ __attribute__((aligned(16))) float a2c[16][kChainMaxN2 + 4];
+	__shared__ __attribute__((aligned(16))) float dz2c[16][kChainMaxN2 + 4];
+	__shared__ __attribute__((aligned(16))) float dz3c[16][20];
+	__shared__ float part[4][16][17];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+	const int n0 = blockIdx.x * 16, n1 = p.n1, n2 = p.n2, n3 = p.n3, B = p.B;
+	auto mfma4 = [](const float4& a, const float4& b, f32x4 acc) {
+		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+		return acc;
+	};
+	// the 16 columns of A1, transposed into LDS
+	for (int e = tid; e < n1 * 4; e += 256) {
+		const int k = e >> 2, c4 = (e & 3) * 4;
+		const float4 v = *reinterpret_cast<const float4*>(p.A1 + (size_t)k * B + n0 + c4);
+		a1c[c4][k] = v.x; a1c[c4 + 1][k] = v.y; a1c[c4 + 2][k] = v.z; a1c[c4 + 3][k] = v.w;
+	}
+	for (int e = tid; e < 16 * 20; e += 256) (&dz3c[0][0])[e] = 0.f;
+	__syncthreads();
+	// layer 2 (:226-229): row tiles of 16, two per wave at n2 = 128
+	const int nt2 = n2 / 16, per2 = (nt2 + 3) / 4;
+	f32x4 z2[2];
+	for (int t = 0; t < 2; t++) {
+		const int mt = wave * per2 + t;
+		z2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+		if (t >= per2 || mt >= nt2) continue;
+		const int r0 = mt * 16;
+		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+		const float* wrow = p.W2 + (size_t)(r0 + li) * n1 + 4 * lq;
+		for (int kb = 0; kb < n1; kb += 16)
+			acc = mfma4(*reinterpret_cast<const float4*>(wrow + kb), *reinterpret_cast<const float4*>(&a1c[li][kb + 4 * lq]), acc);
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int row = r0 + 4 * lq + r;
+			const float z = acc[r] + p.b2[row];
+			const float a = z < 0.f ? 0.f : z;
+			p.Z2[(size_t)row * B + n0 + li] = z; p.A2[(size_t)row * B + n0 + li] = a;
+			a2c[li][row] = a;
+			z2[t][r] = z;
+		}
+	}
+	__syncthreads();
+	// output layer (:231-234, 260-268): one 16 x 16 tile, K cut over the four waves, partial tiles folded in wave order
+	{
+		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+		for (int kb = wave * 16; kb < n2; kb += 64) {
+			float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (li < n3) a = *reinterpret_cast<const float4*>(p.W3 + (size_t)li * n2 + kb + 4 * lq);
+			acc = mfma4(a, *reinterpret_cast<const float4*>(&a2c[li][kb + 4 * lq]), acc);
+		}
+#pragma unroll
+		for (int r = 0; r < 4; r++) part[wave][4 * lq + r][li] = acc[r];
+	}
+	__syncthreads();
+	if (tid < 16) {
+		const int c = tid, col = n0 + tid;
+		float z[16];
+		float mx = -INFINITY;
+		for (int r = 0; r < n3; r++) {
+			z[r] = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + p.b3[r];
+			p.Z3[(size_t)r * B + col] = z[r];
+			mx = fmaxf(mx, z[r]);
+		}
+		float sum = 0.f;
+		for (int r = 0; r < n3; r++) { z[r] = expf(z[r] - mx); sum += z[r]; }
+		int pred = 0; float best = 0.f; double loss = 0.0;
+		for (int r = 0; r < n3; r++) {
+			const float pr = z[r] / sum, yv = p.Y[(size_t)r * B + col];
+			const float g = (pr - yv) * p.gscale;
+			p.A3[(size_t)r * B + col] = pr; p.dZ3[(size_t)r * B + col] = g;
+			dz3c[c][r] = g;
+			if (p.sm_loss) {   // loss / accuracy bookkeeping, :237-257 (see the softmax tail of the wave-split-K GEMM)
+				if (pr > best) { best = pr; pred = r; }
+				if (yv != 0.f) loss += -1.0 * ((double)yv * log((double)pr + 1e-15));
+			}
+		}
+		if (p.sm_loss) { p.sm_loss[col] += loss; p.sm_correct[col] += p.Y[(size_t)pred * B + col] == 1.f ? 1u : 0u; }
+	}
+	if (!p.backward) return;
+	__syncthreads();
+	// dZ2 = (W3^T dZ3) (.) relu'(Z2) (:273-278): the classes are the contraction (n3 <= 16: one group of four MFMAs), same row tiles as layer 2
+	for (int t = 0; t < 2; t++) {
+		const int mt = wave * per2 + t;
+		if (t >= per2 || mt >= nt2) continue;
+		const int r0 = mt * 16;
+		float4 a;
+		a.x = 4 * lq + 0 < n3 ? p.W3[(size_t)(4 * lq + 0) * n2 + r0 + li] : 0.f; a.y = 4 * lq + 1 < n3 ? p.W3[(size_t)(4 * lq + 1) * n2 + r0 + li] : 0.f;
+		a.z = 4 * lq + 2 < n3 ? p.W3[(size_t)(4 * lq + 2) * n2 + r0 + li] : 0.f; a.w = 4 * lq + 3 < n3 ? p.W3[(size_t)(4 * lq + 3) * n2 + r0 + li] : 0.f;
+		f32x4 acc = mfma4(a, *reinterpret_cast<const float4*>(&dz3c[li][4 * lq]), f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int row = r0 + 4 * lq + r;
+			const float v = z2[t][r] > 0.f ? acc[r] : 0.f * acc[r];
+			p.dZ2[(size_t)row * B + n0 + li] = v;
+			dz2c[li][row] = v;
+		}
+	}
+	__syncthreads();
+	// dZ1 = (W2^T dZ2) (.) relu'(Z1) (:284-289): row tiles of 16 over n1, four per wave at n1 = 256
+	const int nt1 = n1 / 16, per1 = (nt1 + 3) / 4;
+	for (int t = 0; t < per1; t++) {
+		const int mt = wave * per1 + t;
+		if (mt >= nt1) break;
+		const int r0 = mt * 16;
+		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+		const float* wcol = p.W2 + (size_t)(4 * lq) * n1 + r0 + li;    // W2^T[m][k] = W2[k][m]
+		for (int kb = 0; kb < n2; kb += 16) {
+			const float* w = wcol + (size_t)kb * n1;
+			const float4 a = make_float4(w[0], w[n1], w[2 * (size_t)n1], w[3 * (size_t)n1]);
+			acc = mfma4(a, *reinterpret_cast<const float4*>(&dz2c[li][kb + 4 * lq]), acc);
+		}
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int row = r0 + 4 * lq + r;
+			const float m = p.Z1[(size_t)row * B + n0 + li];
+			p.dZ1[(size_t)row * B + n0 + li] = m > 0.f ? acc[r] : 0.f * acc[r];
+		}
+	}
+}
+}  // namespace
+
 static bla_status dev_alloc(bla_mnist_nn* nn, float** p, size_t floats) {
 	void* q = nullptr;
 	BLA_HIP(hipMalloc(&q, (floats ? floats : 1) * sizeof(float)));
@@ -165,7 +308,13 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 
 /* Z1 = W1 (x / 255) + b1, A1 = relu; Z2, A2 likewise; Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) / n0; with the
  * loss / accuracy accumulators fed from the output layer's launch when enabled (model/mnist_nn.c:218-268). */
-static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x_raw, const float* d_y) {
+static bool can_chain(const bla_mnist_nn* nn) {
+	static const bool on = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return !(e && e[0] == '0'); }();
+	const int n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
+	return on && n1 % 16 == 0 && n1 <= kChainMaxN1 && n2 % 16 == 0 && n2 <= kChainMaxN2 && n3 <= 16 && B % 16 == 0 && nn->n[0] % 4 == 0;
+}
+
+static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x_raw, const float* d_y, bool with_backward) {
 	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
 	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
 	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
@@ -174,6 +323,13 @@ static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x
 	bla_gemm_epilogue ep = {};
 	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
 	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, d_x_raw, B, nn->a1, B, &ep); if (st) return st;         // :221-224
+	if (can_chain(nn)) {   // everything column-local that follows, forward and backward, in one launch
+		ChainArgs c = {nn->a1, nn->z1, W2, b2, W3, b3, d_y, nn->z2, nn->a2, nn->z3, nn->a3, nn->dz3, nn->dz2, nn->dz1, n1, n2, n3, B, with_backward ? 1 : 0,
+		               (float)(1 / (double)n0), nn->metrics_on ? nn->m_loss : nullptr, nn->metrics_on ? nn->m_correct : nullptr};
+		hipLaunchKernelGGL(mnist_chain_kernel, dim3(B / 16), dim3(256), 0, s, c);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
+	}
 	ep.alpha = 1.f; ep.bias_row = b2; ep.pre_act = nn->z2;
 	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;          // :226-229
 	// output layer: Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) * (1/n0)   (:231-234,260-268;
@@ -211,7 +367,24 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	const float xs = 1 / 255.0F;
 	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
 
-	st = forward_pass(nn, s, d_x_raw, d_y); if (st) return st;
+	st = forward_pass(nn, s, d_x_raw, d_y, true); if (st) return st;
+	if (can_chain(nn)) {
+		// dZ2 and dZ1 came out of the chain launch: what is left are the three weight gradients (+ bias gradients = row sums of dZ), one launch
+		bla_gemm_epilogue e3 = {}, e2 = {}, e1 = {};
+		e3.alpha = 1.f; e3.row_sum_a = fuse_db ? db3 : nullptr;
+		e2.alpha = 1.f; e2.row_sum_a = fuse_db ? db2 : nullptr;
+		e1.alpha = xs; e1.row_sum_a = fuse_db ? db1 : nullptr;
+		bla_gemm_desc d[3] = {{0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, &e3},        // :267-271
+		                      {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &e2},        // :279-282
+		                      {0, 1, n1, n0, B, nn->dz1, B, d_x_raw, B, dW1, n0, &e1}};      // :290-293 (the 1/255 of :218 folded into alpha)
+		st = bla_gemm_group_f32(s, d, 3); if (st) return st;
+		if (!fuse_db) {
+			st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st;
+			st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st;
+			st = bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode); if (st) return st;
+		}
+		return BLA_OK;
+	}
 
 	// (Measured and not kept: running the layer-3 / layer-2 weight-gradient products on a side stream -- parallel branches of
 	// the captured graph -- to take two launches off the critical path.  The cross-queue dependencies cost more than the
@@ -281,8 +454,17 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 	float *W3 = nn->params + nn->off[4], *b3 = nn->params + nn->off[5];
 	const float* x = d_x_raw ? d_x_raw : nn->x_raw; const float* y = d_y ? d_y : nn->y;
 	const float xs = 1 / 255.0F;
-	bla_status st = forward_pass(nn, s, x, y);
+	bla_status st = forward_pass(nn, s, x, y, true);
 	if (st) return st;
+	if (can_chain(nn)) {   // the three updates W_l += lr dZ_l A_{l-1}^T, b_l += lr rowsum(dZ_l) in one launch (the chain no longer reads W2 / W3)
+		bla_gemm_epilogue u3 = {}, u2 = {}, u1 = {};
+		u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
+		u2.alpha = lr; u2.beta = 1.f; u2.row_sum_a = b2; u2.row_sum_alpha = lr; u2.row_sum_beta = 1.f;
+		u1.alpha = lr * xs; u1.beta = 1.f; u1.row_sum_a = b1; u1.row_sum_alpha = lr; u1.row_sum_beta = 1.f;
+		bla_gemm_desc d[3] = {{0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, W3, n2, &u3}, {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, W2, n1, &u2},
+		                      {0, 1, n1, n0, B, nn->dz1, B, x, B, W1, n0, &u1}};
+		return bla_gemm_group_f32(s, d, 3);
+	}
 	bla_gemm_epilogue em2 = {};
 	em2.alpha = 1.f; em2.relu_mask = nn->z2; em2.ld_mask = B;
 	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st;        // dZ2: last reader of W3
@@ -310,7 +492,7 @@ bla_status bla_mnist_nn_forward(bla_mnist_nn* nn, void* stream, const float* d_x
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
-	return forward_pass(nn, pick_stream(stream), d_x_raw ? d_x_raw : nn->x_raw, d_y ? d_y : nn->y);
+	return forward_pass(nn, pick_stream(stream), d_x_raw ? d_x_raw : nn->x_raw, d_y ? d_y : nn->y, false);
 }
 
 static void drop_graphs(bla_mnist_nn* nn) {

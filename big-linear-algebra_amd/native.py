@@ -104,7 +104,7 @@ SIGNATURES = {
     "bla_mnist_nn_fused_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]),
     "bla_mnist_nn_gather_batch": (_I, [_VP, _VP, _VP, _VP, _I, _VP]), "bla_mnist_nn_forward": (_I, [_VP, _VP, _VP, _VP]),
     "bla_mnist_nn_metrics_enable": (_I, [_VP, _I]), "bla_mnist_nn_metrics_read": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _I]),
-    "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]),
+    "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]), "bla_gemm_group_f32": (_I, [_VP, _VP, _I]),
     "bla_diag_mfma_rate": (_I, [_VP, _I, _I, _I, _VP]),
     "bla_graph_begin": (_I, [_VP]), "bla_graph_end": (_I, [_VP, C.POINTER(_VP)]), "bla_graph_launch": (_I, [_VP, _VP]),
     "bla_graph_destroy": (_I, [_VP]),

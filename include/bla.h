@@ -159,6 +159,9 @@ typedef struct bla_gemm_desc {
 	const bla_gemm_epilogue* ep;   /* may be NULL */
 } bla_gemm_desc;
 BLA_API bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q);
+/* Up to three independent products; three latency-bound ones with K-contiguous operands on both sides (transa = 0, transb = 1: the three
+ * weight gradients of one MNIST-NN step, model/mnist_nn.c:267-292) share ONE launch.  Otherwise identical to separate calls. */
+BLA_API bla_status bla_gemm_group_f32(void* stream, const bla_gemm_desc* descs, int count);
 
 /* Tuning/diagnostics: force a tile configuration (-1 = automatic) and split-K factor (0 = automatic).  Configurations
  * (csrc/bla_gemm.hip): 0-2 register-staged tiles (any shape); 3/4/5/7 direct-to-LDS 128x128x16, 64x64x16, 128x128x32, 128x64x16
