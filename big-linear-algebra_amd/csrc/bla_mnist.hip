@@ -62,19 +62,48 @@ struct ChainArgs {
 	double* sm_loss; unsigned* sm_correct;
 };
 
+// Every weight fragment a stage needs is fetched in ONE batch before the stage's MFMAs (fully unrolled register arrays, compile-time
+// bounds): a load in front of each MFMA group made the chain 33 us of dependent round trips; batched, a stage costs one round trip.
 __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 	__shared__ __attribute__((aligned(16))) float a1c[16][kChainMaxN1 + 4];    // [column][k]: one ds_read_b128 = 4 consecutive k of a lane's column
 	__shared__ __attribute__((aligned(16))) float a2c[16][kChainMaxN2 + 4];
 	__shared__ __attribute__((aligned(16))) float dz2c[16][kChainMaxN2 + 4];
 	__shared__ __attribute__((aligned(16))) float dz3c[16][20];
 	__shared__ float part[4][16][17];
+	constexpr int C1 = kChainMaxN1 / 16, C2 = kChainMaxN2 / 16;   // 16-deep k chunks of the two hidden widths
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
 	const int n0 = blockIdx.x * 16, n1 = p.n1, n2 = p.n2, n3 = p.n3, B = p.B;
+	const int nt2 = n2 / 16, per2 = (nt2 + 3) / 4, nt1 = n1 / 16, per1 = (nt1 + 3) / 4;
 	auto mfma4 = [](const float4& a, const float4& b, f32x4 acc) {
 		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
 		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
 		return acc;
 	};
+	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	// ---- fetch: layer 2's weight rows for this wave's (up to) two row tiles, the output layer's rows for its K chunks, W3^T for dZ2 ----
+	float4 w2a[2][C1];
+#pragma unroll
+	for (int t = 0; t < 2; t++) {
+		const int mt = wave * per2 + t;
+		const bool ok = t < per2 && mt < nt2;
+		const float* wrow = p.W2 + (size_t)((ok ? mt : 0) * 16 + li) * n1 + 4 * lq;
+#pragma unroll
+		for (int c = 0; c < C1; c++) w2a[t][c] = (ok && c * 16 < n1) ? *reinterpret_cast<const float4*>(wrow + c * 16) : zero4;
+	}
+	float4 w3a[2];   // chunks wave, wave + 4 of the output layer's contraction
+#pragma unroll
+	for (int u = 0; u < 2; u++) {
+		const int kb = (wave + 4 * u) * 16;
+		w3a[u] = (li < n3 && kb < n2) ? *reinterpret_cast<const float4*>(p.W3 + (size_t)li * n2 + kb + 4 * lq) : zero4;
+	}
+	float4 w3t[2];   // W3^T fragments of the dZ2 tiles: element j = W3[4 lq + j][row]
+#pragma unroll
+	for (int t = 0; t < 2; t++) {
+		const int mt = wave * per2 + t;
+		const int r0 = ((t < per2 && mt < nt2) ? mt : 0) * 16;
+		w3t[t].x = 4 * lq + 0 < n3 ? p.W3[(size_t)(4 * lq + 0) * n2 + r0 + li] : 0.f; w3t[t].y = 4 * lq + 1 < n3 ? p.W3[(size_t)(4 * lq + 1) * n2 + r0 + li] : 0.f;
+		w3t[t].z = 4 * lq + 2 < n3 ? p.W3[(size_t)(4 * lq + 2) * n2 + r0 + li] : 0.f; w3t[t].w = 4 * lq + 3 < n3 ? p.W3[(size_t)(4 * lq + 3) * n2 + r0 + li] : 0.f;
+	}
 	// the 16 columns of A1, transposed into LDS
 	for (int e = tid; e < n1 * 4; e += 256) {
 		const int k = e >> 2, c4 = (e & 3) * 4;
@@ -83,18 +112,18 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 	}
 	for (int e = tid; e < 16 * 20; e += 256) (&dz3c[0][0])[e] = 0.f;
 	__syncthreads();
-	// layer 2 (:226-229): row tiles of 16, two per wave at n2 = 128
-	const int nt2 = n2 / 16, per2 = (nt2 + 3) / 4;
+	// ---- layer 2 (:226-229): row tiles of 16, two per wave at n2 = 128 ----
 	f32x4 z2[2];
+#pragma unroll
 	for (int t = 0; t < 2; t++) {
 		const int mt = wave * per2 + t;
 		z2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 		if (t >= per2 || mt >= nt2) continue;
 		const int r0 = mt * 16;
 		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-		const float* wrow = p.W2 + (size_t)(r0 + li) * n1 + 4 * lq;
-		for (int kb = 0; kb < n1; kb += 16)
-			acc = mfma4(*reinterpret_cast<const float4*>(wrow + kb), *reinterpret_cast<const float4*>(&a1c[li][kb + 4 * lq]), acc);
+#pragma unroll
+		for (int c = 0; c < C1; c++)
+			if (c * 16 < n1) acc = mfma4(w2a[t][c], *reinterpret_cast<const float4*>(&a1c[li][c * 16 + 4 * lq]), acc);
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int row = r0 + 4 * lq + r;
@@ -105,14 +134,31 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 			z2[t][r] = z;
 		}
 	}
+	// (the next stages' weights that do not fit beside w2a: W2^T for the first dZ1 tile is fetched now, under the output layer)
+	float4 w2t[2][C2];     // two register sets: tile t + 1 is fetched while tile t multiplies
+	float zm[2][4];        // relu'(Z1) inputs of the tile
+	auto fetch_t = [&](int t, float4 (&w)[C2], float (&m)[4]) {
+		const int mt = wave * per1 + t;
+		const bool ok = t < per1 && mt < nt1;
+		const int r0 = (ok ? mt : 0) * 16;
+		const float* wcol = p.W2 + (size_t)(4 * lq) * n1 + r0 + li;    // W2^T[m][k] = W2[k][m]
+#pragma unroll
+		for (int c = 0; c < C2; c++) {
+			const float* q = wcol + (size_t)(c * 16) * n1;
+			w[c] = (ok && c * 16 < n2) ? make_float4(q[0], q[n1], q[2 * (size_t)n1], q[3 * (size_t)n1]) : zero4;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; r++) m[r] = ok ? p.Z1[(size_t)(r0 + 4 * lq + r) * B + n0 + li] : 0.f;
+	};
+	if (p.backward) fetch_t(0, w2t[0], zm[0]);
 	__syncthreads();
-	// output layer (:231-234, 260-268): one 16 x 16 tile, K cut over the four waves, partial tiles folded in wave order
+	// ---- output layer (:231-234, 260-268): one 16 x 16 tile, K cut over the four waves, partial tiles folded in wave order ----
 	{
 		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-		for (int kb = wave * 16; kb < n2; kb += 64) {
-			float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (li < n3) a = *reinterpret_cast<const float4*>(p.W3 + (size_t)li * n2 + kb + 4 * lq);
-			acc = mfma4(a, *reinterpret_cast<const float4*>(&a2c[li][kb + 4 * lq]), acc);
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			const int kb = (wave + 4 * u) * 16;
+			if (kb < n2) acc = mfma4(w3a[u], *reinterpret_cast<const float4*>(&a2c[li][kb + 4 * lq]), acc);
 		}
 #pragma unroll
 		for (int r = 0; r < 4; r++) part[wave][4 * lq + r][li] = acc[r];
@@ -120,18 +166,18 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 	__syncthreads();
 	if (tid < 16) {
 		const int c = tid, col = n0 + tid;
-		float z[16];
 		float mx = -INFINITY;
 		for (int r = 0; r < n3; r++) {
-			z[r] = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + p.b3[r];
-			p.Z3[(size_t)r * B + col] = z[r];
-			mx = fmaxf(mx, z[r]);
+			const float z = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + p.b3[r];
+			part[0][r][c] = z;                       // this thread's own column: read and rewritten by it alone
+			p.Z3[(size_t)r * B + col] = z;
+			mx = fmaxf(mx, z);
 		}
 		float sum = 0.f;
-		for (int r = 0; r < n3; r++) { z[r] = expf(z[r] - mx); sum += z[r]; }
+		for (int r = 0; r < n3; r++) { const float e = expf(part[0][r][c] - mx); part[0][r][c] = e; sum += e; }
 		int pred = 0; float best = 0.f; double loss = 0.0;
 		for (int r = 0; r < n3; r++) {
-			const float pr = z[r] / sum, yv = p.Y[(size_t)r * B + col];
+			const float pr = part[0][r][c] / sum, yv = p.Y[(size_t)r * B + col];
 			const float g = (pr - yv) * p.gscale;
 			p.A3[(size_t)r * B + col] = pr; p.dZ3[(size_t)r * B + col] = g;
 			dz3c[c][r] = g;
@@ -144,15 +190,13 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 	}
 	if (!p.backward) return;
 	__syncthreads();
-	// dZ2 = (W3^T dZ3) (.) relu'(Z2) (:273-278): the classes are the contraction (n3 <= 16: one group of four MFMAs), same row tiles as layer 2
+	// ---- dZ2 = (W3^T dZ3) (.) relu'(Z2) (:273-278): the classes are the contraction (n3 <= 16: one group of four MFMAs) ----
+#pragma unroll
 	for (int t = 0; t < 2; t++) {
 		const int mt = wave * per2 + t;
 		if (t >= per2 || mt >= nt2) continue;
 		const int r0 = mt * 16;
-		float4 a;
-		a.x = 4 * lq + 0 < n3 ? p.W3[(size_t)(4 * lq + 0) * n2 + r0 + li] : 0.f; a.y = 4 * lq + 1 < n3 ? p.W3[(size_t)(4 * lq + 1) * n2 + r0 + li] : 0.f;
-		a.z = 4 * lq + 2 < n3 ? p.W3[(size_t)(4 * lq + 2) * n2 + r0 + li] : 0.f; a.w = 4 * lq + 3 < n3 ? p.W3[(size_t)(4 * lq + 3) * n2 + r0 + li] : 0.f;
-		f32x4 acc = mfma4(a, *reinterpret_cast<const float4*>(&dz3c[li][4 * lq]), f32x4{0.f, 0.f, 0.f, 0.f});
+		f32x4 acc = mfma4(w3t[t], *reinterpret_cast<const float4*>(&dz3c[li][4 * lq]), f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int row = r0 + 4 * lq + r;
@@ -162,25 +206,23 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 		}
 	}
 	__syncthreads();
-	// dZ1 = (W2^T dZ2) (.) relu'(Z1) (:284-289): row tiles of 16 over n1, four per wave at n1 = 256
-	const int nt1 = n1 / 16, per1 = (nt1 + 3) / 4;
-	for (int t = 0; t < per1; t++) {
+	// ---- dZ1 = (W2^T dZ2) (.) relu'(Z1) (:284-289): row tiles of 16 over n1, four per wave at n1 = 256 ----
+	auto tile_t = [&](int t, const float4 (&w)[C2], const float (&m)[4]) {
 		const int mt = wave * per1 + t;
-		if (mt >= nt1) break;
+		if (t >= per1 || mt >= nt1) return;
 		const int r0 = mt * 16;
 		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-		const float* wcol = p.W2 + (size_t)(4 * lq) * n1 + r0 + li;    // W2^T[m][k] = W2[k][m]
-		for (int kb = 0; kb < n2; kb += 16) {
-			const float* w = wcol + (size_t)kb * n1;
-			const float4 a = make_float4(w[0], w[n1], w[2 * (size_t)n1], w[3 * (size_t)n1]);
-			acc = mfma4(a, *reinterpret_cast<const float4*>(&dz2c[li][kb + 4 * lq]), acc);
-		}
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int row = r0 + 4 * lq + r;
-			const float m = p.Z1[(size_t)row * B + n0 + li];
-			p.dZ1[(size_t)row * B + n0 + li] = m > 0.f ? acc[r] : 0.f * acc[r];
-		}
+		for (int c = 0; c < C2; c++)
+			if (c * 16 < n2) acc = mfma4(w[c], *reinterpret_cast<const float4*>(&dz2c[li][c * 16 + 4 * lq]), acc);
+#pragma unroll
+		for (int r = 0; r < 4; r++) p.dZ1[(size_t)(r0 + 4 * lq + r) * B + n0 + li] = m[r] > 0.f ? acc[r] : 0.f * acc[r];
+	};
+	for (int t = 0; t < per1; t += 2) {
+		fetch_t(t + 1, w2t[1], zm[1]);
+		tile_t(t, w2t[0], zm[0]);
+		fetch_t(t + 2, w2t[0], zm[0]);
+		tile_t(t + 1, w2t[1], zm[1]);
 	}
 }
 }  // namespace
