@@ -104,6 +104,19 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 		w3t[t].x = 4 * lq + 0 < n3 ? p.W3[(size_t)(4 * lq + 0) * n2 + r0 + li] : 0.f; w3t[t].y = 4 * lq + 1 < n3 ? p.W3[(size_t)(4 * lq + 1) * n2 + r0 + li] : 0.f;
 		w3t[t].z = 4 * lq + 2 < n3 ? p.W3[(size_t)(4 * lq + 2) * n2 + r0 + li] : 0.f; w3t[t].w = 4 * lq + 3 < n3 ? p.W3[(size_t)(4 * lq + 3) * n2 + r0 + li] : 0.f;
 	}
+	float b2v[2][4];   // biases of this lane's rows
+#pragma unroll
+	for (int t = 0; t < 2; t++) {
+		const int mt = wave * per2 + t;
+		const int r0 = ((t < per2 && mt < nt2) ? mt : 0) * 16;
+#pragma unroll
+		for (int r = 0; r < 4; r++) b2v[t][r] = p.b2[r0 + 4 * lq + r];
+	}
+	float b3v[16], yv[16];   // output layer: bias and this column's labels (threads 0..15 use them)
+	double loss0 = 0.0; unsigned corr0 = 0;
+#pragma unroll
+	for (int r = 0; r < 16; r++) { b3v[r] = (tid < 16 && r < n3) ? p.b3[r] : 0.f; yv[r] = (tid < 16 && r < n3) ? p.Y[(size_t)r * B + n0 + tid] : 0.f; }
+	if (tid < 16 && p.sm_loss) { loss0 = p.sm_loss[n0 + tid]; corr0 = p.sm_correct[n0 + tid]; }
 	// the 16 columns of A1, transposed into LDS
 	for (int e = tid; e < n1 * 4; e += 256) {
 		const int k = e >> 2, c4 = (e & 3) * 4;
@@ -127,7 +140,7 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int row = r0 + 4 * lq + r;
-			const float z = acc[r] + p.b2[row];
+			const float z = acc[r] + b2v[t][r];
 			const float a = z < 0.f ? 0.f : z;
 			p.Z2[(size_t)row * B + n0 + li] = z; p.A2[(size_t)row * B + n0 + li] = a;
 			a2c[li][row] = a;
@@ -165,28 +178,35 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 	}
 	__syncthreads();
 	if (tid < 16) {
+		// (fixed trip counts and values fetched up front: a load behind each store -- the compiler must assume they alias -- made this
+		// tail ten dependent round trips long)
 		const int c = tid, col = n0 + tid;
+		float z[16];
 		float mx = -INFINITY;
-		for (int r = 0; r < n3; r++) {
-			const float z = ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + p.b3[r];
-			part[0][r][c] = z;                       // this thread's own column: read and rewritten by it alone
-			p.Z3[(size_t)r * B + col] = z;
-			mx = fmaxf(mx, z);
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			z[r] = r < n3 ? ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + b3v[r] : -INFINITY;
+			mx = fmaxf(mx, z[r]);
 		}
-		float sum = 0.f;
-		for (int r = 0; r < n3; r++) { const float e = expf(part[0][r][c] - mx); part[0][r][c] = e; sum += e; }
-		int pred = 0; float best = 0.f; double loss = 0.0;
-		for (int r = 0; r < n3; r++) {
-			const float pr = part[0][r][c] / sum, yv = p.Y[(size_t)r * B + col];
-			const float g = (pr - yv) * p.gscale;
-			p.A3[(size_t)r * B + col] = pr; p.dZ3[(size_t)r * B + col] = g;
-			dz3c[c][r] = g;
-			if (p.sm_loss) {   // loss / accuracy bookkeeping, :237-257 (see the softmax tail of the wave-split-K GEMM)
-				if (pr > best) { best = pr; pred = r; }
-				if (yv != 0.f) loss += -1.0 * ((double)yv * log((double)pr + 1e-15));
+		float e[16], sum = 0.f;
+#pragma unroll
+		for (int r = 0; r < 16; r++) { e[r] = r < n3 ? expf(z[r] - mx) : 0.f; sum += e[r]; }
+		int pred = 0; float best = 0.f, ypred = yv[0]; double loss = 0.0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			if (r < n3) {
+				const float pr = e[r] / sum;
+				const float g = (pr - yv[r]) * p.gscale;
+				p.Z3[(size_t)r * B + col] = z[r]; p.A3[(size_t)r * B + col] = pr; p.dZ3[(size_t)r * B + col] = g;
+				dz3c[c][r] = g;
+				if (p.sm_loss) {   // loss / accuracy bookkeeping, :237-257 (see the softmax tail of the wave-split-K GEMM)
+					if (pr > best) { best = pr; pred = r; ypred = yv[r]; }
+					if (yv[r] != 0.f) loss += -1.0 * ((double)yv[r] * log((double)pr + 1e-15));
+				}
 			}
 		}
-		if (p.sm_loss) { p.sm_loss[col] += loss; p.sm_correct[col] += p.Y[(size_t)pred * B + col] == 1.f ? 1u : 0u; }
+		(void)pred;
+		if (p.sm_loss) { p.sm_loss[col] = loss0 + loss; p.sm_correct[col] = corr0 + (ypred == 1.f ? 1u : 0u); }
 	}
 	if (!p.backward) return;
 	__syncthreads();
