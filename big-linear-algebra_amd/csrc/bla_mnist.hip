@@ -371,7 +371,11 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 /* Z1 = W1 (x / 255) + b1, A1 = relu; Z2, A2 likewise; Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) / n0; with the
  * loss / accuracy accumulators fed from the output layer's launch when enabled (model/mnist_nn.c:218-268). */
 static bool can_chain(const bla_mnist_nn* nn) {
-	static const bool on = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return !(e && e[0] == '0'); }();
+	// OFF unless BLA_MNIST_CHAIN=1: measured SLOWER than the launches it replaces (chain 31 us + first layer 6.4 + grouped weight gradients 8.4 =
+	// 45.8 us per step against 32.0 us for six launches).  Every workgroup has to stream all of W2 twice (256 KB through ONE CU's memory path),
+	// and only batch / 16 = 16 CUs work; the five separate launches spread the same bytes over the whole chip.  Kept (and tested) as the
+	// record of that experiment; the three-product grouped launch it brought along is used by nothing else yet.
+	static const bool on = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return e && e[0] == '1'; }();
 	const int n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
 	return on && n1 % 16 == 0 && n1 <= kChainMaxN1 && n2 % 16 == 0 && n2 <= kChainMaxN2 && n3 <= 16 && B % 16 == 0 && nn->n[0] % 4 == 0;
 }
