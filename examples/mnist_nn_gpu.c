@@ -228,14 +228,19 @@ static void train(int num_epochs, int batch, int colsum_mode) {
 	}
 	for (int r = 0; r < gpus && gpus > 1; r++) { use(&rep[r]); CHECK(bla_dp_connect(rep[r].dp, handles)); }
 
+	int* next_order = NULL;
 	for (int i = 0; i < num_epochs; i++) {
 		const float epoch_learn_rate = -SGD_LEARN_RATE_MULTIPLIER;       /* :186 (a float) */
-		memset(store.sampled, 0, (size_t)N);                             /* :189-191 */
-		store.num_sampled = 0;
 		const double t0 = now_s();
-		rng_begin();
-		int* order = take_order(&store, N);                              /* the N draws of :205, in order */
-		rng_end();
+		int* order = next_order;
+		if (!order) {
+			memset(store.sampled, 0, (size_t)N);                         /* :189-191 */
+			store.num_sampled = 0;
+			rng_begin();
+			order = take_order(&store, N);                               /* the N draws of :205, in order */
+			rng_end();
+		}
+		next_order = NULL;
 		for (int r = 0; r < gpus; r++) { use(&rep[r]); CHECK(bla_memcpy_h2d(rep[r].d_order, order, (size_t)N * sizeof(int), NULL)); CHECK(bla_stream_sync(NULL)); }
 		if (getenv("BLA_MNIST_SELFCHECK")) {     /* debugging aid: what the device holds against what the host sent */
 			use(&rep[0]);
@@ -267,6 +272,13 @@ static void train(int num_epochs, int batch, int colsum_mode) {
 				if (gpus == 1) CHECK(bla_mnist_nn_fused_step(nn, NULL, NULL, NULL, epoch_learn_rate, colsum_mode));
 				else CHECK(bla_mnist_nn_dp_step_direct(nn, rep[r].dp, NULL, epoch_learn_rate, colsum_mode));
 			}
+		}
+		if (i + 1 < num_epochs) {      /* the next epoch's draws do not depend on this epoch's results: make them while the GPUs work */
+			memset(store.sampled, 0, (size_t)N);
+			store.num_sampled = 0;
+			rng_begin();
+			next_order = take_order(&store, N);
+			rng_end();
 		}
 		double epoch_avg_loss = 0, epoch_avg_accuracy = 0;
 		for (int r = 0; r < gpus; r++) {
