@@ -310,6 +310,25 @@ BLA_API bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out,
                                            const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
                                            int cin, int cout, int k, int tdim, int group_size);
 
+/* ---- lib/layer.h on the device, batched: feed_forward (lib/layer.c:6-20) and back_propagate_errors with its recursion
+ * (:48-107) for `batch` samples (columns) at once, parameters resident in one bucket (W_1, b_1, W_2, b_2, ...; W_l is n_l x n_{l-1}).  The
+ * reference's activation callbacks become one of a few device functions; with batch = 1 the arithmetic is layer.c's step by step, with more
+ * columns the weight / bias steps are summed over the columns (all gradients taken at the weights as they were before the call). */
+enum { BLA_LAYER_ACT_IDENTITY = 0, BLA_LAYER_ACT_SCALE = 1 /* a = p x, a' = p (main.c:7-17 with p = 0.1) */, BLA_LAYER_ACT_RELU = 2,
+       BLA_LAYER_ACT_LEAKY = 3 /* a = x < 0 ? p x : x */ };
+typedef struct bla_layer_net bla_layer_net;
+/* sizes[num_layers] incl. the input layer; acts / act_params [num_layers - 1] for the computing layers */
+BLA_API bla_status bla_layer_net_create(bla_layer_net** out, const int* sizes, int num_layers, int batch, const int* acts, const float* act_params);
+BLA_API bla_status bla_layer_net_destroy(bla_layer_net* m);
+BLA_API size_t bla_layer_net_param_count(const bla_layer_net* m);
+BLA_API float* bla_layer_net_params(bla_layer_net* m);
+BLA_API float* bla_layer_net_weights(bla_layer_net* m, int layer);     /* device, layer >= 1 */
+BLA_API float* bla_layer_net_biases(bla_layer_net* m, int layer);
+BLA_API float* bla_layer_net_nodes(bla_layer_net* m, int layer);       /* [n_layer][batch] after a forward pass */
+BLA_API float* bla_layer_net_raw_nodes(bla_layer_net* m, int layer);
+BLA_API bla_status bla_layer_net_forward_f32(bla_layer_net* m, void* stream, const float* d_x /* [n_0][batch] */);
+BLA_API bla_status bla_layer_net_backward_f32(bla_layer_net* m, void* stream, const float* d_expect /* [n_L][batch] */, float learn_rate);
+
 /* ---- the U-Net of model/cifar_unet.c assembled from the blocks above: forward() (:1099-1166) and backward() (:1351-1436) for one image.
  * 18 ResNet blocks, 5 self-attention blocks, 3 stride-2 convolutions, 3 nearest-neighbour up-samplings (+ a convolution where the widths of the
  * two resolutions differ), 4 skip concatenations, output group norm + ReLU + convolution.  Parameters and gradients live in two flat buckets;
