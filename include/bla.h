@@ -326,6 +326,7 @@ BLA_API float* bla_layer_net_weights(bla_layer_net* m, int layer);     /* device
 BLA_API float* bla_layer_net_biases(bla_layer_net* m, int layer);
 BLA_API float* bla_layer_net_nodes(bla_layer_net* m, int layer);       /* [n_layer][batch] after a forward pass */
 BLA_API float* bla_layer_net_raw_nodes(bla_layer_net* m, int layer);
+/* d_x is read again by the backward pass (it is the first computing layer's a_prev, lib/layer.c:67): keep it valid until then */
 BLA_API bla_status bla_layer_net_forward_f32(bla_layer_net* m, void* stream, const float* d_x /* [n_0][batch] */);
 BLA_API bla_status bla_layer_net_backward_f32(bla_layer_net* m, void* stream, const float* d_expect /* [n_L][batch] */, float learn_rate);
 

@@ -71,8 +71,9 @@ def test_batch_sums_the_single_column_steps(pkg, ora):
     h = make(pkg, sizes, B, 3, 0.25)
     for i in range(3):
         put(pkg, L.bla_layer_net_weights(h, i + 1), ws[i]); put(pkg, L.bla_layer_net_biases(h, i + 1), bs[i])
-    chk(L.bla_layer_net_forward_f32(h, None, pkg.to_device(x).ptr))
-    chk(L.bla_layer_net_backward_f32(h, None, pkg.to_device(e).ptr, lr))
+    dx, de = pkg.to_device(x), pkg.to_device(e)      # the input has to outlive the backward pass (it is the first layer's a_prev)
+    chk(L.bla_layer_net_forward_f32(h, None, dx.ptr))
+    chk(L.bla_layer_net_backward_f32(h, None, de.ptr, lr))
     w64 = [w.astype(np.float64) for w in ws]; b64 = [b.astype(np.float64) for b in bs]
     dw = [np.zeros_like(w) for w in w64]; db = [np.zeros_like(b) for b in b64]
     for c in range(B):
