@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//    front of any LDS read that follows an LDS-DMA.
 	// the half-slab interleaved pipeline: always for 4x4 blocks per wave (256x256, 128x512), on request (HS) for 2x2 (128x128)
 	// (the padded-copy convolution modes 3 / 4 run on it too: their gather is one more address per DMA instruction, dealt out between MFMAs like the rest)
-	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && (TM == 2 || TM == 4) && (TN == 2 || TN == 4))) && (KK == 2 || KK == 4) &&
+	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && TM >= 2 && TM <= 4 && TN >= 2 && TN <= 4)) && (KK == 2 || KK == 4) &&
 	                          (GATHER == 0 || ((GATHER == 3 || GATHER == 4) && HS)) && !PERSIST && NBUF == 2;
 	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
@@ -728,9 +728,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 #pragma unroll
 					for (int r = 0; r < 16; r++) {
 						const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-						const int row = m0 + wm0 + (AKC ? im * 32 + i : TM * i + im);
+						const int row = m0 + wm0 + ((AKC || TM == 3) ? im * 32 + i : TM * i + im);   // (three blocks: not interleaved, see the fragment reads)
 						float* cp = p.C + (size_t)row * p.ldc + n0 + wn0;
-						if (BKC) {
+						if (BKC || TN == 3) {
 #pragma unroll
 							for (int in = 0; in < TN; in++) cp[in * 32 + l31] = p.alpha * acc[im][in][r];
 						} else if (TN == 4) {   // four consecutive columns per lane
@@ -801,18 +801,20 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		unsigned a_ad[KK], b_ad[KK];
 #pragma unroll
 		for (int kk = 0; kk < KK; kk++) {
-			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + TM * l31) * 4;
-			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + TN * l31)) * 4;
+			a_ad[kk] = lds0 + (AKC ? AI::off(wm0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BM + wm0 + (TM == 3 ? 1 : TM) * l31) * 4;
+			b_ad[kk] = lds0 + (A_SZ + (BKC ? BI::off(wn0 + l31, kk * 2 + h) : (kk * 8 + 4 * h) * BN + wn0 + (TN == 3 ? 1 : TN) * l31)) * 4;
 		}
 		struct Frag {
 			v4f ka[TM], kb[TN];   // K-contiguous: [block], elements = k-offset j
 			vra ra[4]; vrb rb[4]; // row-contiguous: [k-offset j], elements = block
+			float sa[4][TM], sb[4][TN];   // row-contiguous with three blocks (192-wide tiles): 12-byte reads would be unaligned, so the blocks keep
+			                              // 32 consecutive rows each and a lane's three elements come as three dword reads
 		};
 		Frag P, Q;
 		constexpr int UA = AKC ? TM : 4, UB = BKC ? TN : 4, NU = UA + UB;   // fragment-read units per k-part
 		constexpr int NM = 4 * TM * TN;                                       // MFMAs per k-part
-		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.ka[im][j] : f.ra[j][im]; };
-		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.kb[in][j] : f.rb[j][in]; };
+		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.ka[im][j] : TM == 3 ? f.sa[j][im] : f.ra[j][im]; };
+		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.kb[in][j] : TN == 3 ? f.sb[j][in] : f.rb[j][in]; };
 		auto mf1 = [&](const Frag& f, int idx) {   // idx-th MFMA of a k-part: j-major, then im, in
 			const int j = idx / (TM * TN), im = (idx % (TM * TN)) / TN, in = idx % TN;
 			acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(f, im, j), opb(f, in, j), acc[im][in], 0, 0, 0);
@@ -821,23 +823,37 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			if (u < UA) {
 				const int x = u;
 				const unsigned ad = buf + a_ad[kk];
-				if (AKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ka[x]) : "v"(ad), "n"(x * 32 * BK * 4));
-				else if (TM == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
+				if constexpr (AKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ka[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else if constexpr (TM == 3) {
+#pragma unroll
+					for (int b = 0; b < 3; b++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sa[x][b]) : "v"(ad), "n"((x * BM + b * 32) * 4));
+				} else if constexpr (TM == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
 				else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
 			} else {
 				const int x = u - UA;
 				const unsigned ad = buf + b_ad[kk];
-				if (BKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.kb[x]) : "v"(ad), "n"(x * 32 * BK * 4));
-				else if (TN == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.rb[x]) : "v"(ad), "n"(x * BN * 4));
+				if constexpr (BKC) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.kb[x]) : "v"(ad), "n"(x * 32 * BK * 4));
+				else if constexpr (TN == 3) {
+#pragma unroll
+					for (int b = 0; b < 3; b++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sb[x][b]) : "v"(ad), "n"((x * BN + b * 32) * 4));
+				} else if constexpr (TN == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.rb[x]) : "v"(ad), "n"(x * BN * 4));
 				else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.rb[x]) : "v"(ad), "n"(x * BN * 4));
 			}
 		};
 		auto land = [&](Frag& f) {   // every read into f has returned; the empty statements make each register's later uses depend on the wait
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-			for (int x = 0; x < UA; x++) { if (AKC) asm volatile("" : "+v"(f.ka[x])); else asm volatile("" : "+v"(f.ra[x])); }
+			for (int x = 0; x < UA; x++) {
+				if constexpr (AKC) asm volatile("" : "+v"(f.ka[x]));
+				else if constexpr (TM == 3) { asm volatile("" : "+v"(f.sa[x][0])); asm volatile("" : "+v"(f.sa[x][1])); asm volatile("" : "+v"(f.sa[x][2])); }
+				else asm volatile("" : "+v"(f.ra[x]));
+			}
 #pragma unroll
-			for (int x = 0; x < UB; x++) { if (BKC) asm volatile("" : "+v"(f.kb[x])); else asm volatile("" : "+v"(f.rb[x])); }
+			for (int x = 0; x < UB; x++) {
+				if constexpr (BKC) asm volatile("" : "+v"(f.kb[x]));
+				else if constexpr (TN == 3) { asm volatile("" : "+v"(f.sb[x][0])); asm volatile("" : "+v"(f.sb[x][1])); asm volatile("" : "+v"(f.sb[x][2])); }
+				else asm volatile("" : "+v"(f.rb[x]));
+			}
 		};
 		// slab t in buffer t&1.  One uniform body for every slab: past the end the fetch cursor stays on the last slab (re-fetched
 		// into a buffer nobody reads again) and the "next" fragments are stale LDS that is never multiplied -- so there is no tail
@@ -1392,7 +1408,9 @@ static const Config kConfigs[] = {
 	{128, 128, 16, 256, true, "glds128x128x16h"},   // the same pipeline on the 128x128 tile (whole tiles, plain epilogue)
 	{128, 256, 16, 256, true, "glds128x256x16h"},   // ... and on 128x256 (waves 2x2, each 64x128): +8 % on 128 x 1152 x 65536, behind elsewhere
 	{16, 16, 16, 256, false, "wsk16x16"},       // wave-split-K on 16x16 tiles (MFMA 16x16x4): forced form of what config 6 picks by itself for few tiles
+	{192, 192, 16, 256, true, "glds192x192x16h"},   // the half-slab pipeline on 192x192 (waves 2x2, each 96x96 = 3x3 blocks): 3072^2 is exactly 256 of them
 };
+static constexpr int kCfgHs192 = 17;
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 static int g_force_config = -1, g_force_split = 0;
@@ -1628,15 +1646,17 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
 			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
 			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
-			const int cand[5] = {3, 7, 4, 11, 13};
-			const double eff[5] = {1.0, 0.95, 0.87, 1.03, 1.03};
-			// 256x256 (config 11): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C only
+			const int cand[7] = {3, 7, 4, 11, 13, 14, kCfgHs192};
+			const double eff[7] = {1.0, 0.95, 0.87, 1.03, 1.03, 1.0, 1.03};
+			// Half-slab pipeline (configs 11, 13, 14, 17): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C
+			// only.  The tile is picked so that the tile count is a whole number of rounds over the CUs: 4096^2 = 256 tiles of 256x256, 3072^2 = 256
+			// of 192x192 (147.6 TFLOP/s against 128 on 64x64 tiles), 2048^2 = 256 of 128x128 (134.6 against 125.7 on 128x64).
 			const bool big_ok = k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
 			                    !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !a.row_sum_a;
 			double best = 0;
-			for (int i = 0; i < 5; i++) {
+			for (int i = 0; i < 7; i++) {
 				const Config& cc = kConfigs[cand[i]];
-				if (i >= 3 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;   // 256x256 / 128x512: whole tiles, plain epilogue
+				if (i >= 3 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;
 				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
 				long rounds = (t + cus - 1) / cus;
 				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
@@ -1726,7 +1746,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			if (splits > 32) splits = 32;
 		}
 	}
-	if (cfg >= 11 && cfg <= 15) {   // half-slab pipeline: whole tiles only (the epilogue has no bounds checks), one pass over K
+	if ((cfg >= 11 && cfg <= 15) || cfg == kCfgHs192) {   // half-slab pipeline: whole tiles only (the epilogue has no bounds checks), one pass over K
 		BLA_REQUIRE(m % c.bm == 0 && n % c.bn == 0 && k >= 2 * c.bk && ldc % 4 == 0 && (uintptr_t)C % 16 == 0, BLA_ERR_INVALID,
 		            "gemm config %d (%s) needs m, n multiples of the tile, k >= %d and a 16-byte aligned C", cfg, c.name, 2 * c.bk);
 		a.rc_global = 0;   // buffer_load ... lds for every operand: 149.7 vs 146.6 TFLOP/s on NN 4096^3 in this kernel
@@ -1776,7 +1796,8 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		case 12: e = launch_glds<256, 256, 32, 2, 2>(a, akc, bkc, grid, s); break;
 		case 13: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;
 		case 14: e = launch_glds<128, 128, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;
-		default: e = launch_glds<128, 256, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 15
+		case 15: e = launch_glds<128, 256, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;
+		default: e = launch_glds<192, 192, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 17
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");
 	static const char* kModeName[] = {"full", "vec", "scalar"};

@@ -60,7 +60,7 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
@@ -81,6 +81,8 @@ def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
             shapes = [(256, 32, 256), (512, 48, 256), (256, 160, 768), (512, 512, 512)]
         if cfg == 15:        # 128x256 tiles, half-slab pipeline, 2x4 blocks per wave
             shapes = [(128, 32, 256), (256, 48, 512), (128, 160, 768), (384, 256, 256)]
+        if cfg == 17:        # 192x192 tiles, half-slab pipeline, 3x3 blocks per wave
+            shapes = [(192, 32, 192), (384, 48, 192), (192, 160, 576), (384, 256, 384)]
         if cfg == 14:        # 128x128 tiles, half-slab pipeline
             shapes = [(128, 32, 128), (256, 48, 384), (128, 160, 640), (384, 256, 512)]
         if cfg == 13:        # 128x512 tiles

@@ -15,10 +15,21 @@ ap.add_argument("--layouts", default="nn")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--split", type=int, default=0)
+ap.add_argument("--warm", type=float, default=1.0, help="seconds of 4096^3 products before the first measurement (the clocks ramp for about that long; 0 = cold)")
 a = ap.parse_args()
 bla = load_pkg(); bla.init(0); L = bla.lib(); chk = bla.native.check
 st = L.bla_default_stream()
 e0, e1 = C.c_void_p(), C.c_void_p(); chk(L.bla_event_create(C.byref(e0))); chk(L.bla_event_create(C.byref(e1)))
+if a.warm > 0:
+    import time
+    wa = bla.to_device(uniform(1, (4096, 4096), dtype=np.float32)); wc = bla.empty((4096, 4096))
+    t0 = time.time()
+    while time.time() - t0 < a.warm:
+        for _ in range(20):
+            bla.gemm(wa, wa, wc, stream=st)
+        bla.sync()
+    del wa, wc
+    print(f"# warmed up for {a.warm:.1f} s of 4096^3 products", flush=True)
 for spec in a.sizes.split(","):
     dims = [int(x) for x in spec.split("x")]
     m, k, n = (dims * 3)[:3] if len(dims) == 1 else dims
