@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 					const int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 					const int col = n0 + wn0 + TN * l31;              // TN consecutive pixels of one image (HWo % 4 == 0)
 					const int b = col / p.g_HWo, rr = col - b * p.g_HWo;
-					float* cp = p.C + (size_t)b * p.M * p.g_HWo + (size_t)row * p.g_HWo + rr;
+					float* cp = (p.splits > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.N : p.C) + (size_t)b * p.M * p.g_HWo + (size_t)row * p.g_HWo + rr;   // slabs are C-shaped
 					if (TN == 4) *reinterpret_cast<float4*>(cp) = make_float4(acc[im][0][r], acc[im][1][r], acc[im][TN > 2 ? 2 : 0][r], acc[im][TN > 3 ? 3 : 0][r]);
 					else *reinterpret_cast<float2*>(cp) = make_float2(acc[im][0][r], acc[im][1][r]);
 				}
@@ -1380,6 +1380,25 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_triple_nt_kernel(GemmArgs p,
 }
 
 // Sums the split-K slabs in split order (deterministic) and applies the epilogue.
+// Plain epilogue on a contiguous C: 16 bytes per thread, eight slab loads in flight (the sum still runs in split order).
+__global__ void __launch_bounds__(64) gemm_splitk_reduce4_kernel(GemmArgs p) {
+	const size_t total4 = (size_t)p.M * p.N / 4;
+	const float4* slab = reinterpret_cast<const float4*>(p.slab);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+		float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+		int z = 0;
+		for (; z + 8 <= p.splits; z += 8) {
+			float4 v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = slab[(size_t)(z + u) * total4 + i];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+		}
+		for (; z < p.splits; z++) { const float4 v = slab[(size_t)z * total4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+		reinterpret_cast<float4*>(p.C)[i] = make_float4(p.alpha * s.x, p.alpha * s.y, p.alpha * s.z, p.alpha * s.w);
+	}
+}
+static hipError_t launch_splitk_reduce(const GemmArgs& r, hipStream_t s);
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
 	size_t total = (size_t)p.M * p.N;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1387,6 +1406,19 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs p) {
 		for (int z = 0; z < p.splits; z++) s += p.slab[(size_t)z * total + i];
 		epilogue_store(p, (int)(i / p.N), (int)(i % p.N), s);
 	}
+}
+
+static hipError_t launch_splitk_reduce(const GemmArgs& r, hipStream_t s) {
+	const size_t total = (size_t)r.M * r.N;
+	const bool plain = !r.bias_row && !r.bias_col && !r.pre_act && r.act == BLA_ACT_NONE && !r.relu_mask && r.beta == 0.f;
+	if (plain && r.ldc == r.N && total % 4 == 0 && (uintptr_t)r.C % 16 == 0 && (uintptr_t)r.slab % 16 == 0) {
+		size_t blocks = (total / 4 + 63) / 64;
+		hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(64), 0, s, r);
+	} else {
+		size_t blocks = (total + 255) / 256;
+		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, r);
+	}
+	return hipGetLastError();
 }
 
 struct Config { int bm, bn, bk, threads; bool glds; const char* name; };
@@ -1513,6 +1545,18 @@ static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
 	if (splits < 1) splits = 1;
 	return (int)((slabs + splits - 1) / splits) * 16;
 }
+// Forward / data gradient on small feature maps (8x8, 4x4: fewer 128x128 tiles than CUs): the contraction over the taps is cut so that about
+// one workgroup sits on every CU, at least 8 slabs each; the slabs have the shape of the output and are summed flat.
+int gather3_splits(int M, int N, int K) {
+	if (!gather_hs(3, M, N)) return 1;
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	const long tiles = (long)(M / 128) * (N / 128), slabs = K / 16;
+	long splits = cus / tiles;
+	if (splits > slabs / 8) splits = slabs / 8;
+	if (splits < 1) splits = 1;
+	const long per = (slabs + splits - 1) / splits;
+	return (int)((slabs + per - 1) / per);
+}
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 	if (mode != 2 && mode != 4) return 1;
 	const long K = (long)batch * HWo;
@@ -1535,8 +1579,8 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
 	a.g_img = img; a.g_zero = zero_word(); a.g_ktab = ktab; a.g_ntab = ntab; a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
 	a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
-	const int splits = gather_gemm_splits(mode, batch, M, N, HWo);
-	a.k_per_split = (mode == 2 || mode == 4) ? gather_k_per_split(mode, batch, M, N, HWo) : K;
+	const int splits = mode == 3 ? gather3_splits(M, N, K) : gather_gemm_splits(mode, batch, M, N, HWo);
+	a.k_per_split = (mode == 2 || mode == 4) ? gather_k_per_split(mode, batch, M, N, HWo) : mode == 3 ? (K / 16 + splits - 1) / splits * 16 : K;
 	a.splits = splits; a.slab = nullptr;
 	if (splits > 1) {
 		void* ws;
@@ -1558,11 +1602,8 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	if (splits > 1) {
 		GemmArgs r = a;
 		if (mode == 4) { r.M = N; r.N = M; }   // the slabs hold the transposed tile: [split][N][M] -> C [N][M]
-		size_t total = (size_t)M * N;
-		unsigned blocks = (unsigned)((total + 255) / 256);
-		if (blocks > 2048u) blocks = 2048u;
-		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, r);
-		BLA_HIP(hipGetLastError());
+		if (mode == 3) r.ldc = r.N;            // C-shaped slabs ([image][M][HWo]): a flat sum
+		BLA_HIP(launch_splitk_reduce(r, s));
 	}
 	return BLA_OK;
 }
@@ -1804,11 +1845,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 	snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_%s_%c%c_%s_splitk%d", c.name, transa ? 't' : 'n', transb ? 't' : 'n',
 	         c.glds ? "dma" : kModeName[mode], splits);
 	if (splits > 1) {
-		size_t total = (size_t)m * n;
-		unsigned blocks = (unsigned)((total + 255) / 256);
-		if (blocks > 2048u) blocks = 2048u;
-		hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
-		e = hipGetLastError();
+		e = launch_splitk_reduce(a, s);
 		if (e != hipSuccess) return hip_fail(e, "gemm_splitk_reduce_kernel launch");
 	}
 	if (deferred_row_sum) return window_sum(stream, A, m, k, lda, deferred_row_sum);

@@ -41,6 +41,7 @@ inline const float* zero_word() { return reinterpret_cast<const float*>(ctx().ti
 //   mode 3: mode 1 on a zero-padded image copy (stride 1): no bounds checks, 16-byte DMA;  tables hold padded offsets
 //   mode 4: mode 2 transposed on a padded copy (stride 1): M = taps, N = rows of A (= del_y [image][N][HWo]), C [N][M] = the weight gradient
 // tables: {element offset, y | x << 16}.  Needs K % 16 == 0 (mode 2: HWo % 16 == 0), A 16-byte aligned with lda % 4 == 0.
+int gather3_splits(int M, int N, int K);                               // ... of a mode-3 product (forward / data gradient on few tiles)
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo);   // K splits (= slabs of M*N floats in the workspace) gather_gemm will use
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
                        const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride);

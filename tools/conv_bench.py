@@ -49,7 +49,7 @@ for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256
 # batch of 64 images through the same kernels (SURVEY 8(d) cfg 5: "batch-of-64 images (M x 64)"): one launch per pass
 print("\nbatch of 64 images, implicit-GEMM path (one launch per pass; FLOPs = 64 x the single-image figure)", flush=True)
 B = 64
-for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256, 256, 3, 1), (32, 128, 256, 3, 2)]:
+for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256, 256, 3, 1), (4, 256, 256, 3, 1), (32, 128, 256, 3, 2), (16, 256, 256, 3, 2)]:
     w = h; ho = -(-h // s); hw = ho * ho; kkc = k * k * cin
     x = bla.to_device(rng.uniform(-1, 1, (B, cin, h, w)).astype(np.float32)); kern = bla.to_device(rng.uniform(-.1, .1, (cout, cin, k, k)).astype(np.float32))
     dy = bla.to_device(rng.uniform(-1, 1, (B, cout, ho, ho)).astype(np.float32))
