@@ -983,8 +983,21 @@ bla_status bla_conv_backward_f32(void* stream, const float* d_del_y, const float
 
 /* Device-resident convolution without the ConvData workspaces: out [F][Ho][Wo] = conv(x [C][H][W], kern [F][C][k][k]),
  * same values as conv()'s `output` (lib/conv.c:205-212, intended composition), any stride. */
+// The adds the U-Net puts behind a convolution, for a batch in one pass: out[b][c][:] += bias[b * bias_stride + c] (bias_stride 0: one bias set for
+// every image), out2 = out + add.
+__global__ void __launch_bounds__(kThreads) conv_epilogue_kernel(float* __restrict__ out, const float* __restrict__ bias, int bias_stride, const float* __restrict__ add,
+                                                                  float* __restrict__ out2, int f_n, int hw, size_t total) {
+	for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {
+		const size_t row = e / hw;
+		const int b = (int)(row / f_n), c = (int)(row - (size_t)b * f_n);
+		float v = out[e];
+		if (bias) { v += bias[(size_t)b * bias_stride + c]; out[e] = v; }
+		if (out2) out2[e] = v + add[e];
+	}
+}
+
 static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride,
-                                 const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr) {
+                                 const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr, int ep_bias_stride = 0) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -999,14 +1012,13 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
 	const bool ep = ep_bias || ep_out2;
 	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
-	if (ep && use_tiled_gather(a, batch, 1)) {   // the tiled kernels carry no epilogue: run the adds behind them
+	if (ep && (batch > 1 || use_tiled_gather(a, batch, 1))) {   // the tiled kernels carry no epilogue (and the in-kernel one knows one bias set): one pass behind them
 		st = launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
-		for (int b = 0; b < batch && !st; b++) {
-			float* o = d_out + (size_t)b * f_n * a.N;
-			if (ep_bias) st = bla_add_tile_columns_f32(stream, o, f_n, a.N, ep_bias, 1);
-			if (!st && ep_out2) st = bla_sum_f32(stream, ep_out2 + (size_t)b * f_n * a.N, o, ep_add + (size_t)b * f_n * a.N, (size_t)f_n * a.N);
-		}
-		return st;
+		if (st) return st;
+		const size_t total = (size_t)batch * f_n * a.N;
+		hipLaunchKernelGGL(conv_epilogue_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, d_out, ep_bias, ep_bias_stride, ep_add, ep_out2, f_n, a.N, total);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
 	}
 	a.ep_bias = ep_bias; a.ep_add = ep_add; a.ep_out2 = ep_out2;
 	return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
@@ -1149,8 +1161,8 @@ bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_
 
 namespace bla {
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2) {
-	return conv2d_forward(stream, d_x, d_kern, d_out, 1, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch, int ep_bias_stride) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride);
 }
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
                                    int channels, int group_size, int hw) {

@@ -1368,6 +1368,16 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, Gemm
 	}
 }
 
+// The same product for `batch` operand sets at fixed strides (the per-image products of a batched attention block): blockIdx.y = set.
+template <int T, bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) gemm_f32_wsk_batched_kernel(GemmArgs p, long stride_a, long stride_b, long stride_c, long stride_pre) {
+	__shared__ __attribute__((aligned(16))) WskShared sh;
+	const long z = blockIdx.y;
+	p.A += z * stride_a; p.B += z * stride_b; p.C += z * stride_c;
+	if (p.pre_act) p.pre_act += z * stride_pre;
+	wsk_body<T, AKC, BKC, true, true>(p, (int)blockIdx.x, 0, sh);
+}
+
 // Three independent products of the same layout class (A and B both K-contiguous: the three weight gradients dW_l = dZ_l . A_{l-1}^T of one
 // MNIST-NN step, model/mnist_nn.c:267-292) in ONE launch: workgroups [0, t1) run p, [t1, t2) run q, the rest r; each brings its own tile size.
 __global__ void __launch_bounds__(256) gemm_f32_wsk_triple_nt_kernel(GemmArgs p, GemmArgs q, GemmArgs r, int t1, int t2) {
@@ -1446,6 +1456,7 @@ static constexpr int kCfgHs192 = 17;
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 static int g_force_config = -1, g_force_split = 0;
+static thread_local int t_plan_batch = 1;   // bla_gemm_batched_f32: the tile-size choice of the wave-split-K kernel counts the tiles of all sets
 #ifdef BLA_WSK_DIAG
 static unsigned long long* g_diag_stamps = nullptr;
 extern "C" __attribute__((visibility("default"))) void bla_diag_set_stamps(void* p) { g_diag_stamps = (unsigned long long*)p; }
@@ -1738,7 +1749,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			BLA_REQUIRE(can16, BLA_ERR_INVALID, "gemm config 16 (wsk16x16) needs 16-byte loads on both operands, no K split over workgroups and m <= 16 with the fused softmax");
 			tile = 16;
 		} else if (g_force_config == 6) tile = 32;
-		else if (can16 && (forced_tile == 16 || (forced_tile == 0 && tiles32 < tile16_below))) tile = 16;
+		else if (can16 && (forced_tile == 16 || (forced_tile == 0 && tiles32 * t_plan_batch < tile16_below))) tile = 16;
 		a.wsk_tile = tile;
 		a.tiles_m = (m + tile - 1) / tile; a.tiles_n = (n + tile - 1) / tile;
 		const long wtiles = (long)a.tiles_m * a.tiles_n;
@@ -1892,6 +1903,46 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 		if (e == hipSuccess && pq.valid) e = launch_wsk(pq.a, pq.akc, pq.bkc, true, true, dim3((unsigned)tq, 1), s);
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk pair launch");
+	return BLA_OK;
+}
+
+/* C_i = op(A_i) op(B_i) for i < batch, operand i at base + i * stride (stride 0 = shared).  Latency-bound shapes (what a self-attention block over
+ * a batch of images is made of) run as ONE launch of the wave-split-K kernel; anything else is issued set by set.  ep (alpha / beta, bias_row,
+ * bias_col, act; pre_act at stride_pre) is shared by the sets. */
+bla_status bla_gemm_batched_f32(void* stream, int transa, int transb, int m, int n, int k, const float* A, int lda, long stride_a, const float* B, int ldb,
+                                long stride_b, float* C, int ldc, long stride_c, int batch, const bla_gemm_epilogue* ep, long stride_pre) {
+	BLA_REQUIRE(batch >= 1, BLA_ERR_INVALID, "batch %d", batch);
+	BLA_REQUIRE(!ep || (!ep->relu_mask && !ep->row_sum_a && !ep->softmax_grad), BLA_ERR_INVALID, "batched products take alpha / beta, the biases, act and pre_act only");
+	if (batch == 1) return gemm_impl(stream, transa, transb, m, n, k, A, lda, B, ldb, C, ldc, ep, nullptr);
+	WskPlan pl = {};
+	const bool aligned = stride_a % 4 == 0 && stride_b % 4 == 0 && stride_c % 4 == 0 && stride_pre % 4 == 0;
+	t_plan_batch = batch;
+	bla_status st = gemm_impl(stream, transa, transb, m, n, k, A, lda, B, ldb, C, ldc, ep, g_force_config < 0 && g_force_split <= 0 && aligned ? &pl : nullptr);
+	t_plan_batch = 1;
+	if (st) return st;
+	if (pl.valid) {
+		hipStream_t s = pick_stream(stream);
+		const dim3 grid((unsigned)(pl.a.tiles_m * pl.a.tiles_n), (unsigned)batch);
+#define BLA_B(T, AK, BK_) hipLaunchKernelGGL((gemm_f32_wsk_batched_kernel<T, AK, BK_>), grid, dim3(256), 0, s, pl.a, stride_a, stride_b, stride_c, stride_pre)
+#define BLA_BT(AK, BK_) do { if (pl.a.wsk_tile == 16) BLA_B(16, AK, BK_); else BLA_B(32, AK, BK_); } while (0)
+		if (pl.akc && !pl.bkc) BLA_BT(true, false);
+		else if (pl.akc && pl.bkc) BLA_BT(true, true);
+		else if (!pl.akc && !pl.bkc) BLA_BT(false, false);
+		else BLA_BT(false, true);
+#undef BLA_BT
+#undef BLA_B
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk_batched_kernel launch");
+		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk_batched_%c%c_%dx%d_x%d", transa ? 't' : 'n', transb ? 't' : 'n', pl.a.tiles_m * pl.a.tiles_n, pl.a.wsk_tile, batch);
+		return BLA_OK;
+	}
+	// (the first set has been issued by the planning call above)
+	for (int i = 1; i < batch; i++) {
+		bla_gemm_epilogue e2;
+		if (ep) { e2 = *ep; if (e2.pre_act) e2.pre_act += (size_t)i * stride_pre; }
+		st = gemm_impl(stream, transa, transb, m, n, k, A + (size_t)i * stride_a, lda, B + (size_t)i * stride_b, ldb, C + (size_t)i * stride_c, ldc, ep ? &e2 : nullptr, nullptr);
+		if (st) return st;
+	}
 	return BLA_OK;
 }
 

@@ -46,10 +46,10 @@ int gather_gemm_splits(int mode, int batch, int M, int N, int HWo);   // K split
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
                        const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride);
 
-// bla_conv.hip: one image's implicit-GEMM convolution with the adds the U-Net puts behind it folded into the store
-// (out = conv + ep_bias[channel]; ep_out2 = out + ep_add, both optional)
+// bla_conv.hip: implicit-GEMM convolution with the adds the U-Net puts behind it: out = conv + ep_bias[image * ep_bias_stride + channel];
+// ep_out2 = out + ep_add, both optional.  One image: folded into the store; a batch: one pass behind the product.
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0);
 
 // group norm + ReLU + dropout in one pass (relu = max(norm, 0), dropped = drop ? 0 : relu), model/cifar_unet.c:1056-1058
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,

@@ -69,6 +69,34 @@ __global__ void __launch_bounds__(kT) softmax_ddx_kernel(const float* __restrict
 	float d = (float)__shfl(dot, 0, 64);
 	for (int j = lane; j < dim; j += 64) out[(size_t)r * dim + j] = sr[j] * (gr[j] - d);
 }
+// dst[i] = sum over the images of src[b][i] (in image order): weight gradients of a batch from per-image products
+__global__ void __launch_bounds__(kT) batch_sum_kernel(const float* __restrict__ src, float* __restrict__ dst, int batch, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+		float acc = 0.f;
+		int b = 0;
+		for (; b + 8 <= batch; b += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = src[(size_t)(b + u) * n + i];
+#pragma unroll
+			for (int u = 0; u < 8; u++) acc += v[u];
+		}
+		for (; b < batch; b++) acc += src[(size_t)b * n + i];
+		dst[i] = acc;
+	}
+}
+static bla_status batch_sum(void* stream, const float* src, float* dst, int batch, size_t n) {
+	hipLaunchKernelGGL(batch_sum_kernel, dim3(blocks_for(n)), dim3(kT), 0, pick_stream(stream), src, dst, batch, n);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+// Group norm over a batch [B][C][HW]: the groups of one image never reach into the next, so the batch folds into the channel count when the
+// groups divide the channels (B*C channels, same groups) or when an image is one short group (groups of C).  false: ragged, image by image.
+static bool fold_groups(int batch, int c, int group_size, int* channels, int* group) {
+	if (c % group_size == 0) { *channels = batch * c; *group = group_size; return true; }
+	if (c < group_size) { *channels = batch * c; *group = c; return true; }
+	return batch == 1 ? (*channels = c, *group = group_size, true) : false;
+}
 }  // namespace bla
 
 using namespace bla;
@@ -205,6 +233,67 @@ bla_status bla_attention_backward_f32(void* stream, const float* d_del_y, const 
 	return ep_gemm(stream, 0, 1, c, s, d, d_wv, d, del_v, d, d_del_x, s, 1.f, 1.f, nullptr);
 }
 
+/* The same block for a batch of images, x / out [B][C][S], every workspace buffer B times the single-image size.  Each per-image product becomes
+ * one launch over the batch (bla_gemm_batched_f32); the four weight gradients are summed over the images from per-image products (d_partials:
+ * [B][C*d] scratch). */
+static bla_status bgemm(void* s, int ta, int tb, int m, int n, int k, const float* A, int lda, long sa, const float* B, int ldb, long sb, float* C, int ldc, long sc,
+                        int batch, float alpha = 1.f, float beta = 0.f, const float* bias_row = nullptr, float* pre = nullptr, int ld_pre = 0, long spre = 0) {
+	bla_gemm_epilogue ep = {};
+	ep.alpha = alpha; ep.beta = beta; ep.bias_row = bias_row; ep.pre_act = pre; ep.ld_pre = ld_pre;
+	return bla_gemm_batched_f32(s, ta, tb, m, n, k, A, lda, sa, B, ldb, sb, C, ldc, sc, batch, &ep, spre);
+}
+
+bla_status bla_attention_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv, const float* d_w,
+                                             const float* d_bias, const bla_attention_ws* ws, float* d_out, int c, int s, int d) {
+	if (batch == 1) return bla_attention_forward_f32(stream, d_x, d_wq, d_wk, d_wv, d_w, d_bias, ws, d_out, c, s, d);
+	BLA_ENTER();
+	BLA_REQUIRE(batch > 0 && c > 0 && s > 0 && d > 0, BLA_ERR_INVALID, "bad attention shape B=%d C=%d S=%d d=%d", batch, c, s, d);
+	BLA_REQUIRE(d_x && d_wq && d_wk && d_wv && d_w && d_bias && d_out && ws && ws->q && ws->k && ws->v && ws->scores_raw && ws->weights && ws->attention,
+	            BLA_ERR_INVALID, "null operand");
+	const float inv = (float)(1.0 / sqrt((double)d));
+	const long xs = (long)c * s, qs = (long)s * d, ss = (long)s * s;
+	st = bgemm(stream, 1, 0, s, d, c, d_x, s, xs, d_wq, d, 0, ws->q, d, qs, batch); if (st) return st;                       // Q = Z Wq   :1003-1004
+	st = bgemm(stream, 1, 0, s, d, c, d_x, s, xs, d_wk, d, 0, ws->k, d, qs, batch); if (st) return st;
+	st = bgemm(stream, 1, 0, s, d, c, d_x, s, xs, d_wv, d, 0, ws->v, d, qs, batch); if (st) return st;
+	st = bgemm(stream, 0, 1, s, s, d, ws->q, d, qs, ws->k, d, qs, ws->weights, s, ss, batch, inv, 0.f, nullptr, ws->scores_raw, s, ss); if (st) return st;   // :1007-1014
+	st = bla_softmax_rows_f32(stream, ws->weights, batch * s, s); if (st) return st;                                       // :1015
+	st = bgemm(stream, 0, 0, s, d, s, ws->weights, s, ss, ws->v, d, qs, ws->attention, d, qs, batch); if (st) return st;     // :1018
+	return bgemm(stream, 1, 1, c, s, d, d_w, c, 0, ws->attention, d, qs, d_out, s, xs, batch, 1.f, 0.f, d_bias);             // :1019-1021
+}
+
+bla_status bla_attention_backward_batched_f32(void* stream, int batch, const float* d_del_y, const float* d_x, const float* d_wq, const float* d_wk,
+                                              const float* d_wv, const float* d_w, const bla_attention_ws* fw, const bla_attention_ws* g, float* d_partials,
+                                              float* d_del_wq, float* d_del_wk, float* d_del_wv, float* d_del_w, float* d_del_x, int c, int s, int d,
+                                              int jacobian_from_raw) {
+	if (batch == 1)
+		return bla_attention_backward_f32(stream, d_del_y, d_x, d_wq, d_wk, d_wv, d_w, fw, g, d_del_wq, d_del_wk, d_del_wv, d_del_w, d_del_x, c, s, d, jacobian_from_raw);
+	BLA_ENTER();
+	BLA_REQUIRE(batch > 0 && c > 0 && s > 0 && d > 0, BLA_ERR_INVALID, "bad attention shape B=%d C=%d S=%d d=%d", batch, c, s, d);
+	BLA_REQUIRE(d_del_y && d_x && d_wq && d_wk && d_wv && d_w && fw && g && d_partials && d_del_wq && d_del_wk && d_del_wv && d_del_w && d_del_x, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(g->q && g->k && g->v && g->scores_raw && g->weights && g->attention, BLA_ERR_INVALID, "null gradient workspace");
+	const float inv = (float)(1.0 / sqrt((double)d));
+	const long xs = (long)c * s, qs = (long)s * d, ss = (long)s * s, ws_ = (long)c * d;
+	float *del_q = g->q, *del_k = g->k, *del_v = g->v, *del_i = g->scores_raw, *del_s = g->weights, *del_p = g->attention;
+	st = bgemm(stream, 1, 1, d, c, s, fw->attention, d, qs, d_del_y, s, xs, d_partials, c, ws_, batch); if (st) return st;      // del_W = sum P^T del_Y'   :1291-1293
+	st = batch_sum(stream, d_partials, d_del_w, batch, (size_t)ws_); if (st) return st;
+	st = bgemm(stream, 1, 1, s, d, c, d_del_y, s, xs, d_w, c, 0, del_p, d, qs, batch); if (st) return st;                       // del_P = del_Y' W^T       :1295-1297
+	st = bgemm(stream, 0, 1, s, s, d, del_p, d, qs, fw->v, d, qs, del_s, s, ss, batch); if (st) return st;                      // del_S = del_P V^T        :1303-1305
+	st = bgemm(stream, 1, 0, s, d, s, fw->weights, s, ss, del_p, d, qs, del_v, d, qs, batch); if (st) return st;                // del_V = S^T del_P        :1299-1301
+	st = bla_softmax_ddx_f32(stream, jacobian_from_raw ? fw->scores_raw : fw->weights, del_s, del_i, batch * s, s); if (st) return st;   // :1307
+	st = bla_scale_f32(stream, del_i, (size_t)batch * s * s, inv); if (st) return st;                                         // :1308
+	st = bgemm(stream, 0, 0, s, d, s, del_i, s, ss, fw->k, d, qs, del_q, d, qs, batch); if (st) return st;                      // :1310
+	st = bgemm(stream, 1, 0, s, d, s, del_i, s, ss, fw->q, d, qs, del_k, d, qs, batch); if (st) return st;                      // :1312-1314
+	st = bgemm(stream, 0, 0, c, d, s, d_x, s, xs, del_k, d, qs, d_partials, d, ws_, batch); if (st) return st;                  // Z^T = X                :1316-1319
+	st = batch_sum(stream, d_partials, d_del_wk, batch, (size_t)ws_); if (st) return st;
+	st = bgemm(stream, 0, 0, c, d, s, d_x, s, xs, del_q, d, qs, d_partials, d, ws_, batch); if (st) return st;
+	st = batch_sum(stream, d_partials, d_del_wq, batch, (size_t)ws_); if (st) return st;
+	st = bgemm(stream, 0, 0, c, d, s, d_x, s, xs, del_v, d, qs, d_partials, d, ws_, batch); if (st) return st;
+	st = batch_sum(stream, d_partials, d_del_wv, batch, (size_t)ws_); if (st) return st;
+	st = bgemm(stream, 0, 1, c, s, d, d_wq, d, 0, del_q, d, qs, d_del_x, s, xs, batch); if (st) return st;                      // del_Z^T, same add order :1322-1334
+	st = bgemm(stream, 0, 1, c, s, d, d_wk, d, 0, del_k, d, qs, d_del_x, s, xs, batch, 1.f, 1.f); if (st) return st;
+	return bgemm(stream, 0, 1, c, s, d, d_wv, d, 0, del_v, d, qs, d_del_x, s, xs, batch, 1.f, 1.f);
+}
+
 bla_status bla_sum_f32(void* stream, float* d_out, const float* d_a, const float* d_b, size_t n) {
 	BLA_ENTER();
 	if (n == 0) return BLA_OK;
@@ -265,6 +354,91 @@ bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const f
 	if (cin != cout) {
 		st = bla_conv2d_backward_f32(stream, d_del_out, d_x, p->res, g->res, sc->g_in, sc->flip, h, w, 1, cin, cout, 1); if (st) return st;
 		return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)cin * hw);
+	}
+	return BLA_OK;
+}
+
+/* The ResNet block for a batch: x / del_x [B][Cin][HW], result / del_out [B][Cout][HW], temb [B][T] (every image its own time step), d_drop
+ * [B][Cout*HW]; the workspace buffers are B times the single-image sizes (tdense [B][Cout], mu / sd [B][groups]).  The convolutions run as
+ * batched implicit GEMMs, the norms over B*C channels; the gradients are summed over the images.  d_dtb: [B][Cout] scratch. */
+static bla_status gn_relu_b(void* stream, int batch, const float* in, float* out, float* sd, float* mu, int c, int gs, int hw, const unsigned char* drop, float* dropped) {
+	int ch, grp;
+	if (fold_groups(batch, c, gs, &ch, &grp))
+		return drop ? group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw) : bla_group_norm_relu_f32(stream, in, out, sd, mu, ch, grp, hw);
+	const int groups = (c + gs - 1) / gs;
+	for (int b = 0; b < batch; b++) {
+		const size_t o = (size_t)b * c * hw;
+		bla_status st = drop ? group_norm_relu_dropout(stream, in + o, out + o, drop + o, dropped + o, sd + (size_t)b * groups, mu + (size_t)b * groups, c, gs, hw)
+		                     : bla_group_norm_relu_f32(stream, in + o, out + o, sd + (size_t)b * groups, mu + (size_t)b * groups, c, gs, hw);
+		if (st) return st;
+	}
+	return BLA_OK;
+}
+static bla_status gn_ddx_b(void* stream, int batch, const float* src, float* dst, const float* data, const float* mu, const float* sd, int c, int gs, int hw,
+                           const float* gate, const float* addend) {
+	int ch, grp;
+	if (fold_groups(batch, c, gs, &ch, &grp)) return group_norm_ddx_gated(stream, src, dst, data, mu, sd, ch, grp, hw, gate, addend);
+	const int groups = (c + gs - 1) / gs;
+	for (int b = 0; b < batch; b++) {
+		const size_t o = (size_t)b * c * hw;
+		bla_status st = group_norm_ddx_gated(stream, src + o, dst + o, data + o, mu + (size_t)b * groups, sd + (size_t)b * groups, c, gs, hw, gate ? gate + o : nullptr,
+		                                     addend ? addend + o : nullptr);
+		if (st) return st;
+	}
+	return BLA_OK;
+}
+
+bla_status bla_group_norm_relu_batched_f32(void* stream, int batch, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels, int group_size, int hw) {
+	return gn_relu_b(stream, batch, d_in, d_out, d_stdevs, d_means, channels, group_size, hw, nullptr, nullptr);
+}
+bla_status bla_group_norm_ddx_gated_batched_f32(void* stream, int batch, const float* d_source, float* d_dest, const float* d_data, const float* d_means,
+                                                const float* d_stdevs, int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend) {
+	return gn_ddx_b(stream, batch, d_source, d_dest, d_data, d_means, d_stdevs, channels, group_size, hw, d_relu_gate, d_addend);
+}
+
+bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                          const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size) {
+	if (batch == 1) return bla_resnet_forward_f32(stream, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size);
+	BLA_ENTER();
+	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
+	BLA_REQUIRE(d_x && d_temb && p && d_drop && ws && d_result && p->conv1 && p->conv2 && p->time_w && p->time_b, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(cin == cout || (p->res && ws->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and workspace");
+	const int hw = h * w;
+	st = gn_relu_b(stream, batch, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw, nullptr, nullptr); if (st) return st;            // :1046-1047
+	bla_gemm_epilogue ep = {};
+	ep.alpha = 1.f; ep.bias_col = p->time_b;
+	st = bla_gemm_f32(stream, 0, 0, batch, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st;      // :1051-1052, one row per image
+	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout); if (st) return st;   // :1048,1053
+	st = gn_relu_b(stream, batch, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw, d_drop, ws->dp); if (st) return st;          // :1056-1058
+	const float* r = d_x;
+	if (cin != cout) {
+		st = bla_conv2d_forward_batched_f32(stream, d_x, p->res, ws->res, batch, h, w, 1, cin, cout, 1); if (st) return st;           // :1062-1066
+		r = ws->res;
+	}
+	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0);            // :1059,1067-1071
+}
+
+bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                           const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
+                                           int w, int cin, int cout, int k, int tdim, int group_size) {
+	if (batch == 1) return bla_resnet_backward_f32(stream, d_del_out, d_x, d_temb, p, ws, g, sc, d_del_x, h, w, cin, cout, k, tdim, group_size);
+	BLA_ENTER();
+	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
+	BLA_REQUIRE(d_del_out && d_x && d_temb && p && ws && g && sc && d_dtb && d_del_x && g->conv1 && g->conv2 && g->time_w && g->time_b && sc->g_out_a &&
+	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
+	const int hw = h * w;
+	st = bla_conv2d_backward_batched_f32(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1); if (st) return st;   // :1186-1189
+	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
+	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
+	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
+	st = batch_sum(stream, d_dtb, g->time_b, batch, (size_t)cout); if (st) return st;
+	st = bla_gemm_f32(stream, 1, 0, tdim, cout, batch, d_temb, tdim, d_dtb, cout, g->time_w, cout, nullptr); if (st) return st;
+	st = bla_conv2d_backward_batched_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, sc->g_in, sc->flip, batch, h, w, k, cin, cout, 1); if (st) return st;   // :1202-1205
+	st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st;
+	if (cin != cout) {                                                                                                                  // :1208-1220
+		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, sc->g_in, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
+		return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)batch * cin * hw);
 	}
 	return BLA_OK;
 }

@@ -108,6 +108,11 @@ SIGNATURES = {
     "bla_mnist_nn_fused_step": (_I, [_VP, _VP, _VP, _VP, _F, _I]),
     "bla_mnist_nn_gather_batch": (_I, [_VP, _VP, _VP, _VP, _I, _VP]), "bla_mnist_nn_forward": (_I, [_VP, _VP, _VP, _VP]),
     "bla_mnist_nn_metrics_enable": (_I, [_VP, _I]), "bla_mnist_nn_metrics_read": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _I]),
+    "bla_gemm_batched_f32": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, C.c_long, _VP, _I, C.c_long, _VP, _I, C.c_long, _I, C.POINTER(Epilogue), C.c_long]),
+    "bla_group_norm_relu_batched_f32": (_I, [_VP, _I] + [_VP] * 4 + [_I] * 3),
+    "bla_group_norm_ddx_gated_batched_f32": (_I, [_VP, _I] + [_VP] * 5 + [_I] * 3 + [_VP] * 2),
+    "bla_attention_forward_batched_f32": (_I, [_VP, _I] + [_VP] * 8 + [_I] * 3), "bla_attention_backward_batched_f32": (_I, [_VP, _I] + [_VP] * 14 + [_I] * 4),
+    "bla_resnet_forward_batched_f32": (_I, [_VP, _I] + [_VP] * 6 + [_I] * 7), "bla_resnet_backward_batched_f32": (_I, [_VP, _I] + [_VP] * 9 + [_I] * 7),
     "bla_gemm_pair_f32": (_I, [_VP, _VP, _VP]), "bla_gemm_group_f32": (_I, [_VP, _VP, _I]),
     "bla_diag_mfma_rate": (_I, [_VP, _I, _I, _I, _VP]),
     "bla_graph_begin": (_I, [_VP]), "bla_graph_end": (_I, [_VP, C.POINTER(_VP)]), "bla_graph_launch": (_I, [_VP, _VP]),

@@ -310,6 +310,31 @@ BLA_API bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out,
                                            const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
                                            int cin, int cout, int k, int tdim, int group_size);
 
+/* The same blocks for a batch of images (what a mini-batch of the reference's one-image-at-a-time training loop computes, gradients summed over the
+ * images): x / out / del_* [B][C][H*W], temb [B][T] (every image its own time step), d_drop [B][Cout*H*W]; every workspace / scratch buffer is B
+ * times its single-image size (tdense [B][Cout], mu / sd [B][groups]).  The convolutions run as batched implicit GEMMs, the norms over B*C
+ * channels, each per-image product of the attention block as one launch over the batch.  batch = 1 is the single-image entry point.
+ * d_partials: [B][C*d] scratch (per-image weight gradients before their sum); d_dtb: [B][Cout] scratch. */
+BLA_API bla_status bla_gemm_batched_f32(void* stream, int transa, int transb, int m, int n, int k, const float* A, int lda, long stride_a, const float* B, int ldb,
+                                        long stride_b, float* C, int ldc, long stride_c, int batch, const bla_gemm_epilogue* ep, long stride_pre);
+BLA_API bla_status bla_group_norm_relu_batched_f32(void* stream, int batch, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels,
+                                                   int group_size, int hw);
+BLA_API bla_status bla_group_norm_ddx_gated_batched_f32(void* stream, int batch, const float* d_source, float* d_dest, const float* d_data, const float* d_means,
+                                                        const float* d_stdevs, int channels, int group_size, int hw, const float* d_relu_gate,
+                                                        const float* d_addend);
+BLA_API bla_status bla_attention_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_wq, const float* d_wk, const float* d_wv,
+                                                     const float* d_w, const float* d_bias, const bla_attention_ws* ws, float* d_out, int c, int s, int d);
+BLA_API bla_status bla_attention_backward_batched_f32(void* stream, int batch, const float* d_del_y, const float* d_x, const float* d_wq, const float* d_wk,
+                                                      const float* d_wv, const float* d_w, const bla_attention_ws* fwd, const bla_attention_ws* grad,
+                                                      float* d_partials, float* d_del_wq, float* d_del_wk, float* d_del_wv, float* d_del_w, float* d_del_x,
+                                                      int c, int s, int d, int jacobian_from_raw);
+BLA_API bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                                  const unsigned char* d_drop, const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k,
+                                                  int tdim, int group_size);
+BLA_API bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb,
+                                                   const bla_resnet_params* p, const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc,
+                                                   float* d_dtb, float* d_del_x, int h, int w, int cin, int cout, int k, int tdim, int group_size);
+
 /* ---- lib/layer.h on the device, batched: feed_forward (lib/layer.c:6-20) and back_propagate_errors with its recursion
  * (:48-107) for `batch` samples (columns) at once, parameters resident in one bucket (W_1, b_1, W_2, b_2, ...; W_l is n_l x n_{l-1}).  The
  * reference's activation callbacks become one of a few device functions; with batch = 1 the arithmetic is layer.c's step by step, with more

@@ -1,0 +1,145 @@
+"""The U-Net's blocks for a batch of images (bla_*_batched_f32): what B runs of the single-image blocks compute -- results per image, weight
+gradients summed over the images.  The single-image blocks are pinned against the reference's own functions (tests/test_resnet.py,
+test_attention.py, test_conv_gpu.py); here the batched launches (batched implicit-GEMM convolutions, group norm over B*C channels, one
+wave-split-K launch per attention product for the whole batch) are held against them, image by image."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from inputs import uniform
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    pkg.init(0)
+    return pkg
+
+
+def close(got, want, tol, tag):
+    scale = np.abs(want).max() + 1e-30
+    err = np.abs(got - want).max()
+    assert err <= tol * scale, (tag, err, scale)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_batched_gemm(dev, ta, tb):
+    """bla_gemm_batched_f32 against float64 products, strides including 0 (a shared operand) and a scaled product with the raw result kept
+    (pre_act); shapes of the attention block and one that leaves the latency-bound kernel (issued set by set)."""
+    L = dev.lib(); chk = dev.native.check
+    for j, (batch, m, n, k, share_b) in enumerate([(5, 64, 16, 32, True), (64, 256, 16, 256, True), (7, 64, 64, 16, False), (3, 36, 20, 44, False), (2, 640, 512, 1536, False)]):
+        a = uniform(300 + j, (batch, k, m) if ta else (batch, m, k), -1, 1, F32)
+        b = uniform(400 + j, ((1 if share_b else batch), n, k) if tb else ((1 if share_b else batch), k, n), -1, 1, F32)
+        da, db = dev.to_device(a), dev.to_device(b)
+        c = dev.empty((batch, m, n)).fill_bytes(0xFF); pre = dev.empty((batch, m, n)).fill_bytes(0xFF)
+        ep = dev.native.Epilogue(); ep.alpha = 0.5; ep.pre_act = pre.ptr; ep.ld_pre = n
+        chk(L.bla_gemm_batched_f32(None, ta, tb, m, n, k, da.ptr, m if ta else k, m * k, db.ptr, k if tb else n, 0 if share_b else n * k, c.ptr, n, m * n, batch,
+                                   C.byref(ep), m * n))
+        A = a.astype(np.float64).transpose(0, 2, 1) if ta else a.astype(np.float64)
+        B = b.astype(np.float64).transpose(0, 2, 1) if tb else b.astype(np.float64)
+        want = 0.5 * (A @ B)
+        close(c.numpy(), want, 2e-6 * np.sqrt(k), (j, "c")); close(pre.numpy(), want, 2e-6 * np.sqrt(k), (j, "pre"))
+
+
+def resnet_case(pkg, batch, cin, cout, hh, tdim, gs, seed):
+    N = pkg.native
+    hw = hh * hh; g1 = (cin + gs - 1) // gs; g2 = (cout + gs - 1) // gs
+    u = lambda k, shape, lo, hi: uniform(seed + k, shape, lo, hi, F32)
+    I = dict(x=u(0, (batch, cin, hh, hh), -1, 1), temb=u(1, (batch, tdim), 0, 1), k1=u(2, (cout, cin, 3, 3), -0.2, 0.2), k2=u(3, (cout, cout, 3, 3), -0.1, 0.1),
+             tw=u(4, (tdim, cout), -0.1, 0.1), tb=u(5, (cout,), -0.1, 0.1), kres=u(6, (cout, cin, 1, 1), -0.3, 0.3) if cin != cout else None,
+             del_out=u(7, (batch, cout, hh, hh), -1, 1))
+    drop = (uniform(seed + 8, (batch, cout, hh, hh), 0, 1, F32) < 0.1).astype(np.uint8)
+    D = {n: pkg.to_device(v) for n, v in I.items() if v is not None}
+    params = N.ResnetParams(D["k1"].ptr, D["k2"].ptr, D["tw"].ptr, D["tb"].ptr, D["kres"].ptr if cin != cout else None)
+
+    def run(b, x, temb, dr, del_out, keep=D):     # (keep: the parameter buffers live as long as this function does -- `params` holds bare addresses)
+        """one forward + backward over b images -> (saved tensors, gradients)"""
+        W = dict(mu1=pkg.empty((b, g1)), sd1=pkg.empty((b, g1)), relu1=pkg.empty((b, cin, hh, hh)), c1=pkg.empty((b, cout, hh, hh)), tdense=pkg.empty((b, cout)),
+                 mu2=pkg.empty((b, g2)), sd2=pkg.empty((b, g2)), relu2=pkg.empty((b, cout, hh, hh)), dp=pkg.empty((b, cout, hh, hh)), c2=pkg.empty((b, cout, hh, hh)),
+                 res=pkg.empty((b, cout, hh, hh)))
+        ws = N.ResnetWs(*[W[n].ptr for n in ("mu1", "sd1", "relu1", "c1", "tdense", "mu2", "sd2", "relu2", "dp", "c2", "res")])
+        result = pkg.empty((b, cout, hh, hh)).fill_bytes(0xFF)
+        dx, dt, dd, dg = pkg.to_device(x), pkg.to_device(temb), pkg.to_device(dr, np.uint8), pkg.to_device(del_out)
+        L = pkg.lib(); chk = N.check
+        chk(L.bla_resnet_forward_batched_f32(None, b, dx.ptr, dt.ptr, C.byref(params), dd.ptr, C.byref(ws), result.ptr, hh, hh, cin, cout, 3, tdim, gs))
+        G = dict(k1=pkg.empty((cout, cin, 3, 3)), k2=pkg.empty((cout, cout, 3, 3)), tw=pkg.empty((tdim, cout)), tb=pkg.empty((cout,)), kres=pkg.empty((cout, cin, 1, 1)))
+        grads = N.ResnetGrads(G["k1"].ptr, G["k2"].ptr, G["tw"].ptr, G["tb"].ptr, G["kres"].ptr if cin != cout else None)
+        S = dict(a=pkg.empty((b, cout, hh, hh)), b=pkg.empty((b, cout, hh, hh)), c=pkg.empty((b, cin, hh, hh)), f=pkg.empty((cout * max(cin, cout) * 9,)))
+        scratch = N.ResnetScratch(S["a"].ptr, S["b"].ptr, S["c"].ptr, S["f"].ptr)
+        dtb = pkg.empty((b, cout)); del_x = pkg.empty((b, cin, hh, hh)).fill_bytes(0xFF)
+        chk(L.bla_resnet_backward_batched_f32(None, b, dg.ptr, dx.ptr, dt.ptr, C.byref(params), C.byref(ws), C.byref(grads), C.byref(scratch), dtb.ptr, del_x.ptr,
+                                              hh, hh, cin, cout, 3, tdim, gs))
+        fw = {n: W[n].numpy() for n in ("relu1", "c1", "tdense", "relu2", "dp", "c2")}; fw["result"] = result.numpy(); fw["del_x"] = del_x.numpy()
+        gr = {n: G[n].numpy() for n in (["k1", "k2", "tw", "tb"] + (["kres"] if cin != cout else []))}
+        return fw, gr
+    return I, drop, run
+
+
+@pytest.mark.parametrize("cfg", [(5, 3, 32, 8, 16, 32), (6, 32, 64, 8, 16, 32), (4, 48, 48, 12, 24, 16), (64, 128, 128, 16, 32, 32), (3, 40, 24, 8, 16, 16)])
+def test_batched_resnet_block(pkg, cfg):
+    """(batch, Cin, Cout, H, T, group): a 3-channel input (one short group per image), Cin != Cout (the 1x1 residual convolution), the batched
+    tiled convolution kernels (64 x 128 @16x16), ragged groups (40 channels in groups of 16: image by image)."""
+    pkg.init(0)
+    batch, cin, cout, hh, tdim, gs = cfg
+    I, drop, run = resnet_case(pkg, batch, cin, cout, hh, tdim, gs, 8100 + 10 * cin)
+    fw, gr = run(batch, I["x"], I["temb"], drop, I["del_out"])
+    sums = None
+    for b in range(batch):
+        if batch > 8 and b % 9:     # the large case: every ninth image in detail (the gradient sums below need all of them: see `full`)
+            continue
+        f1, g1 = run(1, I["x"][b:b + 1], I["temb"][b:b + 1], drop[b:b + 1], I["del_out"][b:b + 1])
+        for n in f1:
+            close(fw[n][b], f1[n][0], 2e-5, (cfg, b, n))
+    full = batch <= 8
+    if full:
+        for b in range(batch):
+            _, g1 = run(1, I["x"][b:b + 1], I["temb"][b:b + 1], drop[b:b + 1], I["del_out"][b:b + 1])
+            sums = {n: g1[n].astype(np.float64) for n in g1} if sums is None else {n: sums[n] + g1[n] for n in g1}
+        for n in sums:
+            assert np.linalg.norm(gr[n] - sums[n]) <= 2e-5 * np.linalg.norm(sums[n]) + 1e-12, (cfg, n)
+    else:   # gradients of the large case: the same batch in two halves must add up to the whole
+        _, ga = run(batch // 2, I["x"][:batch // 2], I["temb"][:batch // 2], drop[:batch // 2], I["del_out"][:batch // 2])
+        _, gb = run(batch - batch // 2, I["x"][batch // 2:], I["temb"][batch // 2:], drop[batch // 2:], I["del_out"][batch // 2:])
+        for n in gr:
+            want = ga[n].astype(np.float64) + gb[n]
+            assert np.linalg.norm(gr[n] - want) <= 2e-5 * np.linalg.norm(want) + 1e-12, (cfg, n)
+
+
+@pytest.mark.parametrize("cfg", [(5, 32, 8, 16), (3, 24, 4, 8), (16, 256, 16, 16)])
+def test_batched_attention_block(pkg, cfg):
+    """(batch, C, H, key dimension): results per image equal to the single-image block, the four weight gradients summed over the images."""
+    pkg.init(0)
+    L = pkg.lib(); chk = pkg.native.check; N = pkg.native
+    batch, c, hh, d = cfg
+    s = hh * hh
+    u = lambda k, shape, lo, hi: uniform(8800 + c + k, shape, lo, hi, F32)
+    x, dy = u(0, (batch, c, s), -1, 1), u(1, (batch, c, s), -1, 1)
+    P = dict(wq=u(2, (c, d), -0.3, 0.3), wk=u(3, (c, d), -0.3, 0.3), wv=u(4, (c, d), -0.3, 0.3), w=u(5, (d, c), -0.3, 0.3), b=u(6, (c,), -0.1, 0.1))
+    DP = {n: pkg.to_device(v) for n, v in P.items()}
+
+    def run(b, xx, dyy):
+        def ws():
+            bufs = dict(q=pkg.empty((b, s, d)), k=pkg.empty((b, s, d)), v=pkg.empty((b, s, d)), scores_raw=pkg.empty((b, s, s)), weights=pkg.empty((b, s, s)),
+                        attention=pkg.empty((b, s, d)))
+            return bufs, N.AttentionWs(*[bufs[n].ptr for n in ("q", "k", "v", "scores_raw", "weights", "attention")])
+        fb, fws = ws(); gb, gws = ws()
+        dx, ddy = pkg.to_device(xx), pkg.to_device(dyy)
+        out = pkg.empty((b, c, s)).fill_bytes(0xFF); del_x = pkg.empty((b, c, s)).fill_bytes(0xFF)
+        chk(L.bla_attention_forward_batched_f32(None, b, dx.ptr, DP["wq"].ptr, DP["wk"].ptr, DP["wv"].ptr, DP["w"].ptr, DP["b"].ptr, C.byref(fws), out.ptr, c, s, d))
+        G = dict(wq=pkg.empty((c, d)), wk=pkg.empty((c, d)), wv=pkg.empty((c, d)), w=pkg.empty((d, c)))
+        part = pkg.empty((b, c * d))
+        chk(L.bla_attention_backward_batched_f32(None, b, ddy.ptr, dx.ptr, DP["wq"].ptr, DP["wk"].ptr, DP["wv"].ptr, DP["w"].ptr, C.byref(fws), C.byref(gws), part.ptr,
+                                                 G["wq"].ptr, G["wk"].ptr, G["wv"].ptr, G["w"].ptr, del_x.ptr, c, s, d, 0))
+        return dict(out=out.numpy(), del_x=del_x.numpy(), weights=fb["weights"].numpy(), raw=fb["scores_raw"].numpy()), {n: G[n].numpy() for n in G}
+    fw, gr = run(batch, x, dy)
+    sums = None
+    for b in range(batch):
+        f1, g1 = run(1, x[b:b + 1], dy[b:b + 1])
+        for n in f1:
+            close(fw[n][b], f1[n][0], 2e-5, (cfg, b, n))
+        sums = {n: g1[n].astype(np.float64) for n in g1} if sums is None else {n: sums[n] + g1[n] for n in g1}
+    for n in sums:
+        assert np.linalg.norm(gr[n] - sums[n]) <= 2e-5 * np.linalg.norm(sums[n]) + 1e-12, (cfg, n)
