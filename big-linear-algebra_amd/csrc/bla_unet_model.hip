@@ -1,5 +1,7 @@
 // bla_unet_model.hip -- the reference's U-Net (model/cifar_unet.c) assembled from the device-resident blocks of bla_unet.hip:
-// forward() (:1099-1166) and backward() (:1351-1436) for one image, parameters and gradients in two flat buckets.
+// forward() (:1099-1166) and backward() (:1351-1436) for one image -- or for a batch of images at once (bla_unet_create_batched: every
+// activation carries a leading image index, every image its own time embedding, the gradients are summed over the images: what a mini-batch
+// of the reference's one-image-at-a-time loop accumulates) -- parameters and gradients in two flat buckets.
 //
 //   18 ResNet blocks (8 down, 2 mid, 8 up), 5 self-attention blocks (two at resolution 2 on the way down, one in the middle, two at
 //   resolution 2 on the way up), 3 stride-2 down-convolutions, 3 nearest-neighbour up-samplings (each followed by a channel-changing
@@ -50,6 +52,7 @@ constexpr size_t kNone = (size_t)-1;
 
 struct bla_unet {
 	bla_unet_config cfg;
+	int batch = 1;
 	int H[4], W[4];
 	std::vector<Tensor> tensors;
 	size_t count = 0, drop_count = 0;
@@ -63,6 +66,7 @@ struct bla_unet {
 	unsigned char* zero_drop = nullptr;
 	// backward
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
+	float *dtb = nullptr, *partials = nullptr;   // batched blocks: per-image time-bias sums [B][Cout], per-image attention weight gradients [B][C*d]
 	bla_resnet_scratch sc = {};
 	bla_attention_ws agrad = {};
 	const float* last_x = nullptr; const float* last_temb = nullptr; const unsigned char* last_drop = nullptr;
@@ -108,21 +112,23 @@ void plan_conv(bla_unet* m, Conv& c, const std::string& name, int cin, int cout,
 	c.kern = present ? add_tensor(m, name, (size_t)cout * cin * c.k * c.k) : kNone;
 }
 bla_status alloc_res(bla_unet* m, Res& r) {
-	const size_t hw = (size_t)r.h * r.w;
-	const int gs = m->cfg.group_size, g1 = (r.cin + gs - 1) / gs, g2 = (r.cout + gs - 1) / gs;
+	const size_t hw = (size_t)r.h * r.w * m->batch;   // (every buffer of the block: B times its single-image size)
+	const int gs = m->cfg.group_size, g1 = (r.cin + gs - 1) / gs * m->batch, g2 = (r.cout + gs - 1) / gs * m->batch;
 	bla_status st;
 	if ((st = dalloc(m, &r.ws.mu1, g1)) || (st = dalloc(m, &r.ws.sd1, g1)) || (st = dalloc(m, &r.ws.relu1, r.cin * hw)) || (st = dalloc(m, &r.ws.c1, r.cout * hw)) ||
-	    (st = dalloc(m, &r.ws.tdense, r.cout)) || (st = dalloc(m, &r.ws.mu2, g2)) || (st = dalloc(m, &r.ws.sd2, g2)) || (st = dalloc(m, &r.ws.relu2, r.cout * hw)) ||
+	    (st = dalloc(m, &r.ws.tdense, (size_t)r.cout * m->batch)) || (st = dalloc(m, &r.ws.mu2, g2)) || (st = dalloc(m, &r.ws.sd2, g2)) || (st = dalloc(m, &r.ws.relu2, r.cout * hw)) ||
 	    (st = dalloc(m, &r.ws.dp, r.cout * hw)) || (st = dalloc(m, &r.ws.c2, r.cout * hw)) || (st = dalloc(m, &r.result, r.cout * hw)))
 		return st;
 	r.ws.res = nullptr;
 	if (r.cin != r.cout) st = dalloc(m, &r.ws.res, r.cout * hw);
 	return st;
 }
-bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s, size_t d) {
+bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s1, size_t d) {
 	bla_status st;
+	const size_t s = s1, ss = s1 * s1 * m->batch;
+	d *= m->batch;
 	if ((st = dalloc(m, &ws.q, s * d)) || (st = dalloc(m, &ws.k, s * d)) || (st = dalloc(m, &ws.v, s * d)) || (st = dalloc(m, &ws.attention, s * d)) ||
-	    (st = dalloc(m, &ws.scores_raw, s * s)) || (st = dalloc(m, &ws.weights, s * s)))
+	    (st = dalloc(m, &ws.scores_raw, ss)) || (st = dalloc(m, &ws.weights, ss)))
 		return st;
 	return BLA_OK;
 }
@@ -131,19 +137,40 @@ bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s, size_t d) {
 __global__ void __launch_bounds__(256) unet_loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ noise, float* __restrict__ g, int n) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] = 2.f * (out[i] - noise[i]);
 }
+// _concat_skip, model/cifar_unet.c:1088-1097, per image: cat[b] = (a[b], skip[b]), both halves n floats
+__global__ void __launch_bounds__(256) unet_concat_kernel(const float* __restrict__ a, const float* __restrict__ skip, float* __restrict__ cat, size_t n, size_t total) {
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = e / (2 * n), r = e - b * 2 * n;
+		cat[e] = r < n ? a[b * n + r] : skip[b * n + r - n];
+	}
+}
+// _split_concat, :1339-1349, per image: the first half is the main path's gradient, the second the skip connection's
+__global__ void __launch_bounds__(256) unet_split_kernel(const float* __restrict__ g_cat, float* __restrict__ g_main, float* __restrict__ g_skip, size_t n, size_t total) {
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = e / (2 * n), r = e - b * 2 * n;
+		const float v = g_cat[e];
+		if (r < n) g_main[b * n + r] = v; else g_skip[b * n + r - n] = v;
+	}
+}
+unsigned grid_of(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 }  // namespace
 
 extern "C" {
 
-bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg) {
+bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg) { return bla_unet_create_batched(out, cfg, 1); }
+
+bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, int batch) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(out && cfg, BLA_ERR_INVALID, "null argument");
+	BLA_REQUIRE(batch >= 1 && batch <= 4096, BLA_ERR_INVALID, "batch %d", batch);
 	BLA_REQUIRE(cfg->image_h > 0 && cfg->image_w > 0 && cfg->in_channels > 0 && cfg->time_dim > 0 && cfg->kernel > 0 && cfg->group_size > 0 && cfg->key_dim > 0 &&
 	            cfg->dims[0] > 0 && cfg->dims[1] > 0 && cfg->dims[2] > 0 && cfg->dims[3] > 0, BLA_ERR_INVALID, "bad U-Net configuration");
 	BLA_REQUIRE(cfg->image_h % 8 == 0 && cfg->image_w % 8 == 0, BLA_ERR_INVALID, "image size must be a multiple of 8 (three halvings, each undone by a x2 up-sampling)");
 	bla_unet* m = new bla_unet();
 	m->cfg = *cfg;
+	m->batch = batch;
+	const size_t B = (size_t)batch;
 	const int* D = cfg->dims;
 	m->H[0] = cfg->image_h; m->W[0] = cfg->image_w;
 	for (int i = 1; i < 4; i++) { m->H[i] = (m->H[i - 1] + 1) / 2; m->W[i] = (m->W[i - 1] + 1) / 2; }   // RESOLUTION_n_HEIGHT, :39-46
@@ -184,52 +211,54 @@ bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg) {
 	if ((st = dalloc(m, &m->params, m->count)) || (st = dalloc(m, &m->grads, m->count))) return fail(st);
 	BLA_HIP(hipMemsetAsync(m->params, 0, m->count * sizeof(float), ctx().stream));
 	BLA_HIP(hipMemsetAsync(m->grads, 0, m->count * sizeof(float), ctx().stream));
-	size_t max_act = 0, max_s = 0, max_flip = 0, max_cout_hw = 0, max_cin_hw = 0;
+	size_t max_act = 0, max_s = 0, max_flip = 0, max_cout_hw = 0, max_cin_hw = 0, max_cd = 1, max_cout = 1;
 	for (Res& r : m->res) {
 		if ((st = alloc_res(m, r))) return fail(st);
-		const size_t hw = (size_t)r.h * r.w;
+		const size_t hw = (size_t)r.h * r.w * B;
 		max_act = std::max(max_act, (size_t)std::max(r.cin, r.cout) * hw);
-		max_cout_hw = std::max(max_cout_hw, r.cout * hw); max_cin_hw = std::max(max_cin_hw, r.cin * hw);
+		max_cout_hw = std::max(max_cout_hw, r.cout * hw); max_cin_hw = std::max(max_cin_hw, r.cin * hw); max_cout = std::max(max_cout, (size_t)r.cout);
 		max_flip = std::max(max_flip, (size_t)r.cout * std::max(r.cin, r.cout) * cfg->kernel * cfg->kernel);
 	}
 	for (Att& a : m->att) {
 		const size_t s = (size_t)a.h * a.w;
-		if ((st = alloc_att_ws(m, a.fwd, s, cfg->key_dim)) || (st = dalloc(m, &a.out, a.c * s))) return fail(st);
+		if ((st = alloc_att_ws(m, a.fwd, s, cfg->key_dim)) || (st = dalloc(m, &a.out, B * a.c * s))) return fail(st);
 		max_s = std::max(max_s, s);
+		max_cd = std::max(max_cd, (size_t)a.c * cfg->key_dim);
 	}
 	for (int i = 0; i < 3; i++) {
 		Conv& c = m->down[i];
-		if ((st = dalloc(m, &c.out, (size_t)c.cout * H[i + 1] * W[i + 1]))) return fail(st);
+		if ((st = dalloc(m, &c.out, B * c.cout * H[i + 1] * W[i + 1]))) return fail(st);
 		max_flip = std::max(max_flip, (size_t)c.cout * c.cin * c.k * c.k);
 		Conv& u = m->up[i];
-		if ((st = dalloc(m, &m->nn[i], (size_t)u.cin * u.h * u.w))) return fail(st);
+		if ((st = dalloc(m, &m->nn[i], B * u.cin * u.h * u.w))) return fail(st);
 		if (u.present) {
-			if ((st = dalloc(m, &u.out, (size_t)u.cout * u.h * u.w))) return fail(st);
+			if ((st = dalloc(m, &u.out, B * u.cout * u.h * u.w))) return fail(st);
 			max_flip = std::max(max_flip, (size_t)u.cout * u.cin * u.k * u.k);
 		}
-		max_act = std::max(max_act, (size_t)u.cin * u.h * u.w);
+		max_act = std::max(max_act, B * u.cin * u.h * u.w);
 	}
 	const int stage_dim[4] = {D[3], D[2], D[1], D[0]}, stage_res[4] = {3, 2, 1, 0};
 	for (int i = 0; i < 4; i++) {
-		const size_t n = (size_t)stage_dim[i] * H[stage_res[i]] * W[stage_res[i]];
+		const size_t n = B * stage_dim[i] * H[stage_res[i]] * W[stage_res[i]];
 		if ((st = dalloc(m, &m->cat[i], 2 * n)) || (st = dalloc(m, &m->gskip[i], n))) return fail(st);
 		max_act = std::max(max_act, 2 * n);
 	}
-	const size_t hw0 = (size_t)H[0] * W[0];
-	const int g0 = (D[0] + cfg->group_size - 1) / cfg->group_size;
+	const size_t hw0 = (size_t)H[0] * W[0] * B;
+	const int g0 = (D[0] + cfg->group_size - 1) / cfg->group_size * batch;
 	if ((st = dalloc(m, &m->outc.out, cfg->in_channels * hw0)) || (st = dalloc(m, &m->out_relu, D[0] * hw0)) || (st = dalloc(m, &m->out_mu, g0)) ||
 	    (st = dalloc(m, &m->out_sd, g0)))
 		return fail(st);
 	max_flip = std::max(max_flip, (size_t)cfg->in_channels * D[0] * cfg->kernel * cfg->kernel);
 	if ((st = dalloc(m, &m->t1, max_act)) || (st = dalloc(m, &m->t2, max_act)) || (st = dalloc(m, &m->t3, max_act)) || (st = dalloc(m, &m->sc.g_out_a, max_cout_hw)) ||
 	    (st = dalloc(m, &m->sc.g_out_b, max_cout_hw)) || (st = dalloc(m, &m->sc.g_in, max_cin_hw)) || (st = dalloc(m, &m->sc.flip, max_flip)) ||
-	    (st = alloc_att_ws(m, m->agrad, max_s, cfg->key_dim)))
+	    (st = alloc_att_ws(m, m->agrad, max_s, cfg->key_dim)) || (st = dalloc(m, &m->dtb, B * max_cout)) || (st = dalloc(m, &m->partials, B * max_cd)))
 		return fail(st);
 	void* z = nullptr;
-	BLA_HIP(hipMalloc(&z, m->drop_count ? m->drop_count : 1));
+	const size_t zero_bytes = m->drop_count ? B * m->drop_count : 1;
+	BLA_HIP(hipMalloc(&z, zero_bytes));
 	m->owned.push_back(z);
 	m->zero_drop = (unsigned char*)z;
-	BLA_HIP(hipMemsetAsync(z, 0, m->drop_count ? m->drop_count : 1, ctx().stream));
+	BLA_HIP(hipMemsetAsync(z, 0, zero_bytes, ctx().stream));
 	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	*out = m;
 	return BLA_OK;
@@ -247,7 +276,8 @@ size_t bla_unet_param_count(const bla_unet* m) { return m ? m->count : 0; }
 float* bla_unet_params(bla_unet* m) { return m ? m->params : nullptr; }
 float* bla_unet_grads(bla_unet* m) { return m ? m->grads : nullptr; }
 float* bla_unet_output(bla_unet* m) { return m ? m->outc.out : nullptr; }
-size_t bla_unet_dropout_count(const bla_unet* m) { return m ? m->drop_count : 0; }
+size_t bla_unet_dropout_count(const bla_unet* m) { return m ? m->drop_count * m->batch : 0; }
+int bla_unet_batch(const bla_unet* m) { return m ? m->batch : 0; }
 int bla_unet_tensor_count(const bla_unet* m) { return m ? (int)m->tensors.size() : 0; }
 
 bla_status bla_unet_tensor_info(const bla_unet* m, int index, size_t* offset, size_t* count, char* name, int name_len) {
@@ -259,7 +289,7 @@ bla_status bla_unet_tensor_info(const bla_unet* m, int index, size_t* offset, si
 	return BLA_OK;
 }
 
-/* forward(), model/cifar_unet.c:1099-1166 */
+/* forward(), model/cifar_unet.c:1099-1166; a batched model takes [B][C][H][W] images and [B][time_dim] embeddings */
 bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, const float* d_time_embedding, const unsigned char* d_drop) {
 	bla_status st = require_ready();
 	if (st) return st;
@@ -267,27 +297,31 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 	const bla_unet_config& c = m->cfg;
 	const int* D = c.dims; const int* H = m->H; const int* W = m->W;
 	const float* P = m->params;
+	const int B = m->batch;
+	hipStream_t s = pick_stream(stream);
 	m->last_x = d_x; m->last_temb = d_time_embedding; m->last_drop = d_drop;
 	auto res = [&](int i, const float* in) -> bla_status {
 		Res& r = m->res[i];
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
-		return bla_resnet_forward_f32(stream, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off, &r.ws, r.result, r.h, r.w, r.cin, r.cout,
-		                              c.kernel, c.time_dim, c.group_size);
+		// the dropout decisions: block by block in forward order, inside a block image by image
+		return bla_resnet_forward_batched_f32(stream, B, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off * B, &r.ws, r.result, r.h, r.w, r.cin,
+		                                      r.cout, c.kernel, c.time_dim, c.group_size);
 	};
 	auto att = [&](int i, const float* in) -> bla_status {
 		Att& a = m->att[i];
-		return bla_attention_forward_f32(stream, in, P + a.wq, P + a.wk, P + a.wv, P + a.wo, P + a.bias, &a.fwd, a.out, a.c, a.h * a.w, c.key_dim);
+		return bla_attention_forward_batched_f32(stream, B, in, P + a.wq, P + a.wk, P + a.wv, P + a.wo, P + a.bias, &a.fwd, a.out, a.c, a.h * a.w, c.key_dim);
 	};
 	auto conv = [&](Conv& k, const float* in) -> bla_status {
-		return bla_conv2d_forward_f32(stream, in, P + k.kern, k.out, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+		return bla_conv2d_forward_batched_f32(stream, in, P + k.kern, k.out, B, k.h, k.w, k.k, k.cin, k.cout, k.stride);
 	};
-	auto concat = [&](int stage, const float* a, const float* skip, size_t n) -> bla_status {   // _concat_skip, :1088-1097
-		bla_status s2 = bla_memcpy_d2d(m->cat[stage], a, n * sizeof(float), stream);
-		return s2 ? s2 : bla_memcpy_d2d(m->cat[stage] + n, skip, n * sizeof(float), stream);
+	auto concat = [&](int stage, const float* a, const float* skip, size_t n) -> bla_status {   // _concat_skip, :1088-1097 (n: floats per image and half)
+		hipLaunchKernelGGL(unet_concat_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, a, skip, m->cat[stage], n, 2 * n * B);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
 	};
 	auto upsample = [&](int i, const float* in, const float** next) -> bla_status {   // _nearest_neighbours (+ the optional convolution), :1125-1131
 		Conv& u = m->up[i];
-		bla_status s2 = bla_nearest_neighbours_f32(stream, in, m->nn[i], u.cin, H[3 - i], W[3 - i], u.h, u.w, 2);
+		bla_status s2 = bla_nearest_neighbours_f32(stream, in, m->nn[i], B * u.cin, H[3 - i], W[3 - i], u.h, u.w, 2);
 		*next = m->nn[i];
 		if (!s2 && u.present) { s2 = conv(u, m->nn[i]); *next = u.out; }
 		return s2;
@@ -317,13 +351,13 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 	TRY(concat(3, next, m->res[1].result, (size_t)D[0] * H[0] * W[0]));
 	TRY(res(16, m->cat[3])); TRY(res(17, m->res[16].result));
 	// output, :1163-1165
-	TRY(bla_group_norm_relu_f32(stream, m->res[17].result, m->out_relu, m->out_sd, m->out_mu, D[0], c.group_size, H[0] * W[0]));
+	TRY(bla_group_norm_relu_batched_f32(stream, B, m->res[17].result, m->out_relu, m->out_sd, m->out_mu, D[0], c.group_size, H[0] * W[0]));
 	TRY(conv(m->outc, m->out_relu));
 	return BLA_OK;
 }
 
-/* backward(), model/cifar_unet.c:1351-1436 (intended wiring, see the head of this file): fills the gradient bucket for the image, time
- * embedding and dropout decisions of the last forward pass. */
+/* backward(), model/cifar_unet.c:1351-1436 (intended wiring, see the head of this file): fills the gradient bucket for the images, time
+ * embeddings and dropout decisions of the last forward pass (summed over the images of a batch). */
 bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise) {
 	bla_status st = require_ready();
 	if (st) return st;
@@ -333,21 +367,22 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 	const int* D = c.dims; const int* H = m->H; const int* W = m->W;
 	const float* P = m->params; float* G = m->grads;
 	const float* temb = m->last_temb;
+	const int B = m->batch;
 	hipStream_t s = pick_stream(stream);
 	// ResNet block i: gradient `g` of its result -> `out` (gradient of its input `x`)
 	auto res = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Res& r = m->res[i];
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
-		return bla_resnet_backward_f32(stream, g, x, temb, &p, &r.ws, &gr, &m->sc, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim, c.group_size);
+		return bla_resnet_backward_batched_f32(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim, c.group_size);
 	};
 	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Att& a = m->att[i];
-		return bla_attention_backward_f32(stream, g, x, P + a.wq, P + a.wk, P + a.wv, P + a.wo, &a.fwd, &m->agrad, G + a.wq, G + a.wk, G + a.wv, G + a.wo, out, a.c,
-		                                  a.h * a.w, c.key_dim, 0);
+		return bla_attention_backward_batched_f32(stream, B, g, x, P + a.wq, P + a.wk, P + a.wv, P + a.wo, &a.fwd, &m->agrad, m->partials, G + a.wq, G + a.wk, G + a.wv,
+		                                          G + a.wo, out, a.c, a.h * a.w, c.key_dim, 0);
 	};
 	auto conv = [&](Conv& k, const float* g, const float* x, float* out) -> bla_status {
-		return bla_conv2d_backward_f32(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+		return bla_conv2d_backward_batched_f32(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride);
 	};
 	// up-sampling stage i backwards: gradient of (the optional convolution's output | the resized map) -> gradient of the map before resizing;
 	// g, tmp and out are three different buffers
@@ -355,54 +390,57 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		Conv& u = m->up[i];
 		const float* gn = g;
 		if (u.present) { bla_status s2 = conv(u, g, m->nn[i], tmp); if (s2) return s2; gn = tmp; }
-		return bla_nearest_neighbours_ddx_f32(stream, gn, out, u.cin, u.h, u.w, H[3 - i], W[3 - i], 2);
+		return bla_nearest_neighbours_ddx_f32(stream, gn, out, B * u.cin, u.h, u.w, H[3 - i], W[3 - i], 2);
 	};
-	auto keep_skip = [&](int stage, const float* g_cat, size_t n) -> bla_status {   // _split_concat, :1339-1349: the second half is the skip's gradient
-		return bla_memcpy_d2d(m->gskip[stage], g_cat + n, n * sizeof(float), stream);
+	// _split_concat, :1339-1349: the first half of a concatenation's gradient goes on along the main path, the second is the skip connection's
+	auto split = [&](int stage, const float* g_cat, float* g_main, size_t n) -> bla_status {
+		hipLaunchKernelGGL(unet_split_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, g_cat, g_main, m->gskip[stage], n, 2 * n * B);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
 	};
 	// three rotating gradient buffers: a block never writes the buffer it reads
 	float *a = m->t1, *b = m->t2, *cbuf = m->t3;
 	const size_t hw0 = (size_t)H[0] * W[0];
 	const size_t n0 = (size_t)D[0] * hw0, n1 = (size_t)D[1] * H[1] * W[1], n2 = (size_t)D[2] * H[2] * W[2], n3 = (size_t)D[3] * H[3] * W[3];
-	const int nout = (int)(c.in_channels * hw0);
-	hipLaunchKernelGGL(unet_loss_grad_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, m->outc.out, d_noise, a, nout);   // :1353-1364
+	const int nout = (int)(c.in_channels * hw0 * B);
+	hipLaunchKernelGGL(unet_loss_grad_kernel, dim3(grid_of((size_t)nout)), dim3(256), 0, s, m->outc.out, d_noise, a, nout);   // :1353-1364
 	BLA_HIP(hipGetLastError());
 	// output processing, :1367-1369: convolution, ReLU gate, group norm
 	TRY(conv(m->outc, a, m->out_relu, b));
-	TRY(group_norm_ddx_gated(stream, b, a, m->res[17].result, m->out_mu, m->out_sd, D[0], c.group_size, (int)hw0, m->out_relu, nullptr));
+	TRY(bla_group_norm_ddx_gated_batched_f32(stream, B, b, a, m->res[17].result, m->out_mu, m->out_sd, D[0], c.group_size, (int)hw0, m->out_relu, nullptr));
 	// fourth up-sampling stage, :1372-1374
 	TRY(res(17, a, m->res[16].result, b)); TRY(res(16, b, m->cat[3], a));
-	TRY(keep_skip(3, a, n0));
+	TRY(split(3, a, b, n0));
 	// third, :1377-1383 (resize and the optional convolution, then attention 2, ResNet 2, attention 1, ResNet 1)
-	TRY(upsample(2, a, b, cbuf));
+	TRY(upsample(2, b, a, cbuf));
 	TRY(att(4, cbuf, m->res[15].result, a)); TRY(res(15, a, m->att[3].out, b)); TRY(att(3, b, m->res[14].result, a)); TRY(res(14, a, m->cat[2], b));
-	TRY(keep_skip(2, b, n1));
+	TRY(split(2, b, a, n1));
 	// second, :1386-1390
-	TRY(upsample(1, b, a, cbuf));
+	TRY(upsample(1, a, b, cbuf));
 	TRY(res(13, cbuf, m->res[12].result, a)); TRY(res(12, a, m->cat[1], b));
-	TRY(keep_skip(1, b, n2));
+	TRY(split(1, b, a, n2));
 	// first, :1393-1397
-	TRY(upsample(0, b, a, cbuf));
+	TRY(upsample(0, a, b, cbuf));
 	TRY(res(11, cbuf, m->res[10].result, a)); TRY(res(10, a, m->cat[0], b));
-	TRY(keep_skip(0, b, n3));
+	TRY(split(0, b, a, n3));
 	// middle, :1400-1402
-	TRY(res(9, b, m->att[2].out, a)); TRY(att(2, a, m->res[8].result, b)); TRY(res(8, b, m->res[7].result, a));
+	TRY(res(9, a, m->att[2].out, b)); TRY(att(2, b, m->res[8].result, a)); TRY(res(8, a, m->res[7].result, b));
 	// fourth down-sampling stage, :1405-1409: the skip's gradient joins the main path's
-	TRY(bla_add_f32(stream, a, m->gskip[0], n3));
-	TRY(res(7, a, m->res[6].result, b)); TRY(res(6, b, m->down[2].out, a));
+	TRY(bla_add_f32(stream, b, m->gskip[0], n3 * B));
+	TRY(res(7, b, m->res[6].result, a)); TRY(res(6, a, m->down[2].out, b));
 	// third, :1412-1417
-	TRY(conv(m->down[2], a, m->res[5].result, b));
-	TRY(bla_add_f32(stream, b, m->gskip[1], n2));
-	TRY(res(5, b, m->res[4].result, a)); TRY(res(4, a, m->down[1].out, b));
+	TRY(conv(m->down[2], b, m->res[5].result, a));
+	TRY(bla_add_f32(stream, a, m->gskip[1], n2 * B));
+	TRY(res(5, a, m->res[4].result, b)); TRY(res(4, b, m->down[1].out, a));
 	// second, :1420-1427
-	TRY(conv(m->down[1], b, m->att[1].out, a));
-	TRY(att(1, a, m->res[3].result, b));
-	TRY(bla_add_f32(stream, b, m->gskip[2], n1));
-	TRY(res(3, b, m->att[0].out, a)); TRY(att(0, a, m->res[2].result, b)); TRY(res(2, b, m->down[0].out, a));
+	TRY(conv(m->down[1], a, m->att[1].out, b));
+	TRY(att(1, b, m->res[3].result, a));
+	TRY(bla_add_f32(stream, a, m->gskip[2], n1 * B));
+	TRY(res(3, a, m->att[0].out, b)); TRY(att(0, b, m->res[2].result, a)); TRY(res(2, a, m->down[0].out, b));
 	// first, :1430-1435
-	TRY(conv(m->down[0], a, m->res[1].result, b));
-	TRY(bla_add_f32(stream, b, m->gskip[3], n0));
-	TRY(res(1, b, m->res[0].result, a)); TRY(res(0, a, m->last_x, b));
+	TRY(conv(m->down[0], b, m->res[1].result, a));
+	TRY(bla_add_f32(stream, a, m->gskip[3], n0 * B));
+	TRY(res(1, a, m->res[0].result, b)); TRY(res(0, b, m->last_x, a));
 	return BLA_OK;
 }
 #undef TRY

@@ -94,6 +94,7 @@ SIGNATURES = {
     "bla_layer_net_param_count": (_SZ, [_VP]), "bla_layer_net_params": (_VP, [_VP]), "bla_layer_net_weights": (_VP, [_VP, _I]),
     "bla_layer_net_biases": (_VP, [_VP, _I]), "bla_layer_net_nodes": (_VP, [_VP, _I]), "bla_layer_net_raw_nodes": (_VP, [_VP, _I]),
     "bla_layer_net_forward_f32": (_I, [_VP, _VP, _VP]), "bla_layer_net_backward_f32": (_I, [_VP, _VP, _VP, _F]),
+    "bla_unet_create_batched": (_I, [C.POINTER(_VP), _VP, _I]), "bla_unet_batch": (_I, [_VP]),
     "bla_unet_create": (_I, [C.POINTER(_VP), _VP]), "bla_unet_destroy": (_I, [_VP]), "bla_unet_param_count": (_SZ, [_VP]),
     "bla_unet_params": (_VP, [_VP]), "bla_unet_grads": (_VP, [_VP]), "bla_unet_output": (_VP, [_VP]), "bla_unet_tensor_count": (_I, [_VP]),
     "bla_unet_tensor_info": (_I, [_VP, _I, C.POINTER(_SZ), C.POINTER(_SZ), C.c_char_p, _I]), "bla_unet_dropout_count": (_SZ, [_VP]),

@@ -365,6 +365,11 @@ BLA_API bla_status bla_layer_net_backward_f32(bla_layer_net* m, void* stream, co
 typedef struct bla_unet_config { int image_h, image_w, in_channels, dims[4], time_dim, kernel, group_size, key_dim; } bla_unet_config;
 typedef struct bla_unet bla_unet;
 BLA_API bla_status bla_unet_create(bla_unet** out, const bla_unet_config* cfg);
+/* The same network for `batch` images per pass: d_x / the output / d_noise are [B][C][H][W], d_time_embedding [B][time_dim] (every image its own
+ * time step), the gradients are summed over the images (what `batch` passes of the reference's one-image loop accumulate).  d_drop: the blocks
+ * in forward order, inside a block image by image.  bla_unet_create = batch 1. */
+BLA_API bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, int batch);
+BLA_API int bla_unet_batch(const bla_unet* m);
 BLA_API bla_status bla_unet_destroy(bla_unet* m);
 BLA_API size_t bla_unet_param_count(const bla_unet* m);         /* floats in each bucket (every tensor starts 16-byte aligned) */
 BLA_API float* bla_unet_params(bla_unet* m);                    /* device */
