@@ -378,6 +378,65 @@ def run_conv(bla, stream, barrier, steps=20, warmup=5):
     return res, (x, kern, dy, out, dk, dx)
 
 
+def run_unet(bla, stream, barrier, steps=5, warmup=2, batch=64):
+    """The whole conv path of BASELINE configs[4] at model level: the reference's U-Net at its own constants (model/cifar_unet.c:26-37: 32x32x3,
+    widths 128/256/256/256, time embedding 512, key dimension 16, groups of 32; 23.9 M parameters) on a batch of CIFAR-shaped images,
+    forward() + backward() (:1099-1166, :1351-1436) device-resident (bla_unet_create_batched).  The fraction prices the convolution FLOPs of the
+    pass (2 MACs forward, twice that backward) against the fp32 MFMA peak; norms, attention and glue ride in the same time."""
+    L = bla.lib(); chk = bla.native.check
+    from inputs import uniform
+
+    class Cfg(C.Structure):
+        _fields_ = [("image_h", C.c_int), ("image_w", C.c_int), ("in_channels", C.c_int), ("dims", C.c_int * 4), ("time_dim", C.c_int), ("kernel", C.c_int),
+                    ("group_size", C.c_int), ("key_dim", C.c_int)]
+    D, k2, c0, hw = [128, 256, 256, 256], 9, 3, [1024, 256, 64, 16]
+    cfg = Cfg(32, 32, c0, (C.c_int * 4)(*D), 512, 3, 32, 16)
+    h = C.c_void_p()
+    chk(L.bla_unet_create_batched(C.byref(h), C.byref(cfg), batch))
+    total = L.bla_unet_param_count(h)
+    flat = np.zeros(total, np.float32)
+    for i in range(L.bla_unet_tensor_count(h)):       # every tensor uniform in +-sqrt(3 / fan-in) (biases +-0.05): activations stay finite
+        off, cnt = C.c_size_t(), C.c_size_t(); name = C.create_string_buffer(96)
+        chk(L.bla_unet_tensor_info(h, i, C.byref(off), C.byref(cnt), name, 96))
+        nm = name.value.decode()
+        fan = 0.05 if nm.endswith("biases") else float(np.sqrt(3.0 / max(1, cnt.value // (D[0] if "down_1" in nm or "up_4" in nm else 256))))
+        flat[off.value:off.value + cnt.value] = uniform(7000 + i, (cnt.value,), -fan, fan, np.float32)
+    chk(L.bla_memcpy_h2d(L.bla_unet_params(h), flat.ctypes.data, flat.nbytes, None)); bla.sync()
+    x = bla.to_device(uniform(41, (batch, c0, 32, 32), -1, 1, np.float32)); temb = bla.to_device(uniform(42, (batch, 512), -1, 1, np.float32))
+    noise = bla.to_device(uniform(43, (batch, c0, 32, 32), -1, 1, np.float32))
+    res = [(c0, D[0], 0), (D[0], D[0], 0), (D[1], D[1], 1), (D[1], D[1], 1), (D[2], D[2], 2), (D[2], D[2], 2)] + [(D[3], D[3], 3)] * 4 + \
+          [(2 * D[3], D[3], 3), (D[3], D[3], 3), (2 * D[2], D[2], 2), (D[2], D[2], 2), (2 * D[1], D[1], 1), (D[1], D[1], 1), (2 * D[0], D[0], 0), (D[0], D[0], 0)]
+    fl = sum(2 * hw[l] * co * (ci * k2 + co * k2 + (ci if ci != co else 0)) for ci, co, l in res)
+    fl += 2 * k2 * (hw[1] * D[0] * D[1] + hw[2] * D[1] * D[2] + hw[3] * D[2] * D[3]) + 2 * k2 * hw[0] * D[1] * D[0] + 2 * k2 * hw[0] * D[0] * c0
+    ev = [C.c_void_p() for _ in range(3)]
+    for e in ev:
+        chk(L.bla_event_create(C.byref(e)))
+    for _ in range(warmup):
+        chk(L.bla_unet_forward_f32(h, stream, x.ptr, temb.ptr, None)); chk(L.bla_unet_backward_f32(h, stream, noise.ptr))
+    barrier()
+    t0 = time.perf_counter(); t_f = t_b = 0.0
+    for _ in range(steps):
+        chk(L.bla_event_record(ev[0], stream)); chk(L.bla_unet_forward_f32(h, stream, x.ptr, temb.ptr, None)); chk(L.bla_event_record(ev[1], stream))
+        chk(L.bla_unet_backward_f32(h, stream, noise.ptr)); chk(L.bla_event_record(ev[2], stream))
+        ms = C.c_float()
+        chk(L.bla_event_elapsed_ms(ev[0], ev[1], C.byref(ms))); t_f += ms.value
+        chk(L.bla_event_elapsed_ms(ev[1], ev[2], C.byref(ms))); t_b += ms.value
+    barrier()
+    wall = time.perf_counter() - t0
+    out = np.empty((batch, c0, 32, 32), np.float32)
+    chk(L.bla_memcpy_d2h(out.ctypes.data, L.bla_unet_output(h), out.nbytes, None)); bla.sync()
+    chk(L.bla_unet_destroy(h))
+    f_ms, b_ms = t_f / steps, t_b / steps
+    tf = 3 * fl * batch / ((f_ms + b_ms) * 1e-3) / 1e12
+    return {"metric": "U-Net (model/cifar_unet.c constants) forward + backward, batch of CIFAR-shaped images", "value": round(steps * batch / wall, 1), "unit": "images/s",
+            "batch": batch, "steps": steps, "warmup": warmup, "parameters": int(total), "forward_ms": round(f_ms, 3), "backward_ms": round(b_ms, 3),
+            "finite_output": bool(np.isfinite(out).all()),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "algorithmic_flops_per_launch": 3 * fl * batch, "note": "convolution FLOPs only (2 MACs forward, twice that backward) over the whole pass"},
+            "cpu_baseline": {"value": round(1 / 29.3, 4), "unit": "images/s", "cores": 1, "kind": "reference",
+                             "sample": "the reference program `cifar_unet train 1`, one image forward + backward: 29.3 s on one core of the build container (BASELINE.md section 2; not re-timed here)"}}
+
+
 def cpu_baseline_conv(arrays, target_seconds=6.0):
     """conv() + conv_ddx() of the reference (lib/conv.c:205-229, restated in oracle/, fp64, 1 core) on single images of the same shape;
     the first image doubles as a correctness check of the batched kernels."""
@@ -411,6 +470,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mnist-steps", type=int, default=300, help="timed steps of the secondary MNIST-NN workload (0 = skip)")
     ap.add_argument("--mnist-warmup", type=int, default=30)
+    ap.add_argument("--unet-steps", type=int, default=5, help="timed forward+backward passes of the batch-64 U-Net under the tertiary workload (0 = skip; N = 1 only)")
     ap.add_argument("--conv-steps", type=int, default=20, help="timed forward+backward passes of the tertiary batched-convolution workload (0 = skip; N = 1 only)")
     args = ap.parse_args()
 
@@ -528,6 +588,13 @@ def main():
             import traceback
             traceback.print_exc()
             ter, conv_arrays = ({"metric": "conv 128->128 k3 s1 @32x32 x64 images", "value": None, "error": repr(e)} if rank == 0 else None), None
+        if ter is not None and args.unet_steps > 0:
+            try:
+                ter["unet_batch_64"] = run_unet(bla, stream, barrier, steps=args.unet_steps)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                ter["unet_batch_64"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, c_cpu, rows = cpu_baseline_gemm(n)
         out["cpu_baseline"] = base

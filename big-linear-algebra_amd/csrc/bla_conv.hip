@@ -1025,6 +1025,130 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 }
 
 
+// ---- data gradient of a stride-2 convolution by output parity (no zero work) ------------------------------------------------------------------
+// del_x[c][y][x] = sum over f and the taps (p, q) with i*2 + p - pt = y, j*2 + q - pl = x of del_y[f][i][j] * K[f][c][p][q].  For the output pixels of
+// one parity class (y = 2u + ry, x = 2v + rx) the taps are a fixed subset (p = p0, p0 + 2, ...; i = u - dp with dp = (p - pt - ry) / 2 >= 0), so the class
+// is a stride-1 correlation of del_y with a sub-kernel: a gathered product over K = F * |P| * |Q| instead of the F * k * k of the zero-dilated form, which
+// multiplies three zeros for every value.  The four classes run as four gathered products on one padded copy of del_y (dp_max zero rows on top, dq_max zero
+// columns on the left) and land in a class-planar buffer that one pass interleaves into del_x.
+struct ParityTaps { int n; int tap[4]; int d[4]; };   // taps of one parity along one axis: kernel index and the (non-negative) source shift
+static ParityTaps parity_taps(int k, int pad, int r) {
+	ParityTaps t = {0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	for (int p = 0; p < k; p++)
+		if ((p - pad - r) % 2 == 0 && p - pad - r >= 0 && t.n < 4) { t.tap[t.n] = p; t.d[t.n] = (p - pad - r) / 2; t.n++; }
+	return t;
+}
+// A_class[c][(f, a, b)] = K[f][c][P.tap[a]][Q.tap[b]] for the four classes, back to back in `out`
+__global__ void __launch_bounds__(kThreads) parity_kernels_kernel(const float* __restrict__ kern, float* __restrict__ out, int f_n, int c_n, int k, ParityTaps p0, ParityTaps p1,
+                                                                   ParityTaps q0, ParityTaps q1) {
+	const int total = f_n * c_n * k * k;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		int cls = 0, base = 0, r = e;
+		for (; cls < 4; cls++) {
+			const int kc = f_n * ((cls >> 1) ? p1.n : p0.n) * ((cls & 1) ? q1.n : q0.n) * c_n;
+			if (r < kc) break;
+			r -= kc; base += kc;
+		}
+		const ParityTaps& P = (cls >> 1) ? p1 : p0;
+		const ParityTaps& Q = (cls & 1) ? q1 : q0;
+		const int kk = f_n * P.n * Q.n, c = r / kk, t = r - c * kk, f = t / (P.n * Q.n), ab = t - f * (P.n * Q.n), a = ab / Q.n, b = ab - a * Q.n;
+		out[base + r] = kern[(((size_t)f * c_n + c) * k + P.tap[a]) * k + Q.tap[b]];
+	}
+}
+__global__ void __launch_bounds__(kThreads) parity_tables_kernel(int2* taps, int2* pix, int f_n, ParityTaps P, ParityTaps Q, int dpmax, int dqmax, int hh, int wh, int hc, int wc) {
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int nt = f_n * P.n * Q.n;
+	if (e < nt) { const int f = e / (P.n * Q.n), ab = e % (P.n * Q.n), a = ab / Q.n, b = ab % Q.n; taps[e] = make_int2((f * hh + dpmax - P.d[a]) * wh + dqmax - Q.d[b], 0); }
+	if (e < hc * wc) { const int u = e / wc, v = e - u * wc; pix[e] = make_int2(u * wh + v, 0); }
+}
+// del_x[b][c][2u + ry][2v + rx] = cls[ry * 2 + rx][b][c][u][v]
+__global__ void __launch_bounds__(kThreads) parity_interleave_kernel(const float* __restrict__ cls, float* __restrict__ out, unsigned planes, int h, int w) {
+	const unsigned hc = h / 2, wc = w / 2;
+	const size_t per = (size_t)planes * hc * wc, total = (size_t)planes * h * (w / 2);
+	for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kThreads) {   // two neighbouring pixels per thread
+		const unsigned v = (unsigned)(e % wc); const size_t t = e / wc; const unsigned y = (unsigned)(t % h); const size_t pc = t / h;
+		const size_t src = (pc * hc + y / 2) * wc + v;
+		const float2 o = make_float2(cls[(size_t)((y & 1) * 2) * per + src], cls[(size_t)((y & 1) * 2 + 1) * per + src]);
+		*reinterpret_cast<float2*>(out + (pc * h + y) * w + 2 * v) = o;
+	}
+}
+struct ParityTables { int device, f_n, k, pt, pl, ho, wo; int2* taps[4]; int2* pix; };
+static std::vector<ParityTables> g_parity;
+
+static bool parity_dgrad_applies(int batch, int h, int w, int k, int c_in, int f_n, int stride, const Geometry& gm) {
+	static const bool off = [] { const char* e = getenv("BLA_CONV_PARITY"); return e && e[0] == '0'; }();
+	if (off || stride != 2 || h % 2 || w % 8 || k > 4 || f_n % 16 || c_in % 128 || ((long)batch * (h / 2) * (w / 2)) % 128) return false;
+	for (int r = 0; r < 2; r++) {   // every tap must belong to a class with a non-negative shift, and the shifted rows must stay inside del_y
+		const ParityTaps P = parity_taps(k, gm.pt, r), Q = parity_taps(k, gm.pl, r);
+		if (P.n == 0 || Q.n == 0) return false;
+	}
+	const ParityTaps a = parity_taps(k, gm.pt, 0), b = parity_taps(k, gm.pt, 1), c = parity_taps(k, gm.pl, 0), d = parity_taps(k, gm.pl, 1);
+	return a.n + b.n == k && c.n + d.n == k && gm.ho == h / 2 && gm.wo == w / 2;
+}
+
+static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, const float* d_kern, float* d_del_x, float* d_scratch, int batch, int h, int w, int k,
+                                         int c_in, int f_n, const Geometry& gm) {
+	const int hc = h / 2, wc = w / 2;
+	ParityTaps P[2] = {parity_taps(k, gm.pt, 0), parity_taps(k, gm.pt, 1)}, Q[2] = {parity_taps(k, gm.pl, 0), parity_taps(k, gm.pl, 1)};
+	int dpmax = 0, dqmax = 0;
+	for (int r = 0; r < 2; r++)
+		for (int i = 0; i < 4; i++) { if (i < P[r].n && P[r].d[i] > dpmax) dpmax = P[r].d[i]; if (i < Q[r].n && Q[r].d[i] > dqmax) dqmax = Q[r].d[i]; }
+	const int hh = gm.ho + dpmax, wh = (gm.wo + dqmax + 3) / 4 * 4;
+	// tables, once per geometry and device
+	const ParityTables* tb = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_table_mu);
+		const int dev = ctx().device;
+		for (const ParityTables& e : g_parity)
+			if (e.device == dev && e.f_n == f_n && e.k == k && e.pt == gm.pt && e.pl == gm.pl && e.ho == gm.ho && e.wo == gm.wo) { tb = &e; break; }
+		if (!tb) {
+			bla_status st = table_build_allowed(s);
+			if (st) return st;
+			ParityTables n = {dev, f_n, k, gm.pt, gm.pl, gm.ho, gm.wo, {nullptr, nullptr, nullptr, nullptr}, nullptr};
+			BLA_HIP(hipMalloc((void**)&n.pix, (size_t)hc * wc * sizeof(int2)));
+			for (int cls = 0; cls < 4; cls++) {
+				const ParityTaps& p = P[cls >> 1]; const ParityTaps& q = Q[cls & 1];
+				const int nt = f_n * p.n * q.n;
+				BLA_HIP(hipMalloc((void**)&n.taps[cls], (size_t)nt * sizeof(int2)));
+				const int cnt = nt > hc * wc ? nt : hc * wc;
+				hipLaunchKernelGGL(parity_tables_kernel, dim3((cnt + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx().stream, n.taps[cls], n.pix, f_n, p, q, dpmax, dqmax, hh,
+				                   wh, hc, wc);
+				BLA_HIP(hipGetLastError());
+			}
+			BLA_HIP(hipStreamSynchronize(ctx().stream));
+			g_parity.push_back(n);
+			tb = &g_parity.back();
+		}
+	}
+	const ParityTables t = *tb;
+	const int N = batch * hc * wc;
+	size_t slab_bytes = 0;
+	for (int cls = 0; cls < 4; cls++) {
+		const int kc = f_n * P[cls >> 1].n * Q[cls & 1].n, sp = gather3_splits(c_in, N, kc);
+		if (sp > 1) slab_bytes = std::max(slab_bytes, ((size_t)sp * c_in * N * sizeof(float) + 255) / 256 * 256);
+	}
+	const size_t copy_floats = (size_t)batch * f_n * hh * wh, cls_floats = (size_t)batch * c_in * hc * wc;
+	BLA_REQUIRE(copy_floats < ((size_t)1 << 29) && cls_floats < ((size_t)1 << 29), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
+	void* ws;
+	bla_status st = ensure_workspace(slab_bytes + (copy_floats + 4 * cls_floats) * sizeof(float) + 64, &ws);   // [slabs][padded del_y][four class planes]
+	if (st) return st;
+	float* padded = (float*)((char*)ws + slab_bytes);
+	float* planes = padded + (copy_floats + 3) / 4 * 4;
+	launch_pad_split(s, d_del_y, padded, (unsigned)(batch * f_n), gm.ho, gm.wo, dpmax, dqmax, 1, (unsigned)hh, (unsigned)wh);
+	hipLaunchKernelGGL(parity_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k, P[0], P[1], Q[0], Q[1]);
+	BLA_HIP(hipGetLastError());
+	size_t a_off = 0;
+	for (int cls = 0; cls < 4; cls++) {
+		const int kc = f_n * P[cls >> 1].n * Q[cls & 1].n;
+		st = gather_gemm(s, 3, batch, c_in, N, kc, d_scratch + a_off, kc, planes + (size_t)cls * cls_floats, hc * wc, padded, t.taps[cls], t.pix, hh, wh, hc * wc, f_n * hh * wh);
+		if (st) return st;
+		a_off += (size_t)c_in * kc;
+	}
+	hipLaunchKernelGGL(parity_interleave_kernel, dim3(grid_for((size_t)batch * c_in * h * (w / 2))), dim3(kThreads), 0, s, planes, d_del_x, (unsigned)(batch * c_in), h, w);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
                                   float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
 	bla_status st = require_ready();
@@ -1073,6 +1197,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 			return BLA_ERR_UNDEFINED;
 		}
 		BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
+		if (parity_dgrad_applies(batch, h, w, k, c_in, f_n, stride, gm)) return conv2d_backward_parity(s, d_del_y, d_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, gm);
 		int total = f_n * c_in * k * k;
 		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
 		BLA_HIP(hipGetLastError());

@@ -255,7 +255,8 @@ def test_batched_conv_equals_per_image_calls(dev, ora, batch):
 
 @pytest.mark.parametrize("shape", [(64, 16, 16, 16, 64, 3, 1), (256, 16, 16, 16, 64, 3, 2), (120, 12, 12, 16, 72, 3, 1), (40, 20, 20, 32, 128, 1, 1),
                                    (128, 32, 32, 16, 128, 3, 2), (64, 32, 32, 16, 128, 3, 1), (96, 14, 18, 16, 128, 3, 2),
-                                   (64, 8, 8, 128, 128, 3, 1), (64, 4, 4, 256, 256, 3, 1)])   # small maps: 32 / 16 tiles, the taps cut over 8 / 16 workgroups
+                                   (64, 8, 8, 128, 128, 3, 1), (64, 4, 4, 256, 256, 3, 1),    # small maps: 32 / 16 tiles, the taps cut over 8 / 16 workgroups
+                                   (8, 16, 16, 128, 32, 3, 2), (4, 8, 16, 128, 48, 3, 2)])    # stride 2 with 128 input channels: data gradient by output parity
 def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
     """Batches big enough to fill the chip with 128x128 tiles run on the LDS-tiled gather kernel (direct-to-LDS 4-byte loads from
     computed addresses, zero padding from a zero word; or, when the output rows are multiples of four pixels, 16-byte loads from the
