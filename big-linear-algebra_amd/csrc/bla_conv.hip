@@ -376,6 +376,8 @@ struct ConvArgs {
 	const float* ep_bias = nullptr;
 	const float* ep_add = nullptr;
 	float* ep_out2 = nullptr;
+	int ep_bias_stride = 0;      // batched tiled forward only: bias set per image
+	bool ep_fused_tiled = false; // the tiled (padded-copy, half-slab) forward kernel applies the epilogue itself
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -753,7 +755,9 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 			if (st) return st;
 			launch_pad_split(s, a.img, padded, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl, a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
 			BLA_HIP(hipGetLastError());
-			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, padded, taps, pix, pg.hh, pg.wh, a.N, (int)(a.g.c * pg.plane_floats));
+			const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
+			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, padded, taps, pix, pg.hh, pg.wh, a.N, (int)(a.g.c * pg.plane_floats),
+			                   a.ep_fused_tiled ? &gep : nullptr);
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
@@ -1012,7 +1016,15 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
 	const bool ep = ep_bias || ep_out2;
 	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
-	if (ep && (batch > 1 || use_tiled_gather(a, batch, 1))) {   // the tiled kernels carry no epilogue (and the in-kernel one knows one bias set): one pass behind them
+	if (ep && (batch > 1 || use_tiled_gather(a, batch, 1))) {
+		// the half-slab forward kernel applies the adds where it stores its tiles (one pass over K, whole tiles); the other tiled kernels carry no
+		// epilogue and the 32x32 kernel's knows one bias set: one pass behind them
+		const PaddedGeom pg = padded_geom(a.g);
+		const bool fits32 = (size_t)batch * a.g.c * pg.plane_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
+		if (use_tiled_gather(a, batch, 1) && fits32 && a.g.wo % 4 == 0 && gather3_fuses_epilogue(a.M, a.N * batch, a.K)) {
+			a.ep_bias = ep_bias; a.ep_bias_stride = ep_bias_stride; a.ep_add = ep_add; a.ep_out2 = ep_out2; a.ep_fused_tiled = true;
+			return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
+		}
 		st = launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
 		if (st) return st;
 		const size_t total = (size_t)batch * f_n * a.N;
@@ -1095,8 +1107,9 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 		for (int i = 0; i < 4; i++) { if (i < P[r].n && P[r].d[i] > dpmax) dpmax = P[r].d[i]; if (i < Q[r].n && Q[r].d[i] > dqmax) dqmax = Q[r].d[i]; }
 	const int hh = gm.ho + dpmax, wh = (gm.wo + dqmax + 3) / 4 * 4;
 	// tables, once per geometry and device
-	const ParityTables* tb = nullptr;
+	ParityTables t;   // (a copy: the cache vector may grow under another caller once the lock is released)
 	{
+		const ParityTables* tb = nullptr;
 		std::lock_guard<std::mutex> lk(g_table_mu);
 		const int dev = ctx().device;
 		for (const ParityTables& e : g_parity)
@@ -1119,8 +1132,8 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 			g_parity.push_back(n);
 			tb = &g_parity.back();
 		}
+		t = *tb;
 	}
-	const ParityTables t = *tb;
 	const int N = batch * hc * wc;
 	size_t slab_bytes = 0;
 	for (int cls = 0; cls < 4; cls++) {

@@ -60,6 +60,9 @@ struct GemmArgs {
 	const float* g_img; const float* g_zero;
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
+	// mode 3 on the half-slab pipeline, one pass over K: the adds the U-Net puts behind a convolution, applied where the tile is stored
+	// (out = product + g_bias[image * g_bias_stride + row]; g_out2 = out + g_add, same layout as out; each optional)
+	const float* g_bias; int g_bias_stride; const float* g_add; float* g_out2;
 	int rc_global;   // host-side only: pick the instantiation that fetches row-contiguous operands with global_load_lds
 	int wsk_tile;    // wave-split-K kernels: 32 (32x32 tiles, MFMA 32x32x2) or 16 (16x16 tiles, MFMA 16x16x4)
 };
@@ -687,16 +690,33 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			return;
 		}
 		if constexpr (GATHER == 3 && HALFSLAB) {   // whole tiles; a lane owns TN consecutive columns (the row-contiguous operand's interleaved blocks)
+			const int col = n0 + wn0 + TN * l31;              // TN consecutive pixels of one image (HWo % 4 == 0)
+			const int b = col / p.g_HWo, rr = col - b * p.g_HWo;
+			const size_t img_off = (size_t)b * p.M * p.g_HWo + rr;
+			float* cbase = (p.splits > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.N : p.C) + img_off;   // slabs are C-shaped
+			const float* bias = p.g_bias ? p.g_bias + (size_t)b * p.g_bias_stride : nullptr;
 #pragma unroll
 			for (int im = 0; im < TM; im++)
 #pragma unroll
 				for (int r = 0; r < 16; r++) {
 					const int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-					const int col = n0 + wn0 + TN * l31;              // TN consecutive pixels of one image (HWo % 4 == 0)
-					const int b = col / p.g_HWo, rr = col - b * p.g_HWo;
-					float* cp = (p.splits > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.N : p.C) + (size_t)b * p.M * p.g_HWo + (size_t)row * p.g_HWo + rr;   // slabs are C-shaped
-					if (TN == 4) *reinterpret_cast<float4*>(cp) = make_float4(acc[im][0][r], acc[im][1][r], acc[im][TN > 2 ? 2 : 0][r], acc[im][TN > 3 ? 3 : 0][r]);
-					else *reinterpret_cast<float2*>(cp) = make_float2(acc[im][0][r], acc[im][1][r]);
+					const size_t o = (size_t)row * p.g_HWo;
+					const float bv = bias ? bias[row] : 0.f;
+					if (TN == 4) {
+						const float4 v = make_float4(acc[im][0][r] + bv, acc[im][1][r] + bv, acc[im][TN > 2 ? 2 : 0][r] + bv, acc[im][TN > 3 ? 3 : 0][r] + bv);
+						*reinterpret_cast<float4*>(cbase + o) = v;
+						if (p.g_out2) {
+							const float4 a4 = *reinterpret_cast<const float4*>(p.g_add + img_off + o);
+							*reinterpret_cast<float4*>(p.g_out2 + img_off + o) = make_float4(v.x + a4.x, v.y + a4.y, v.z + a4.z, v.w + a4.w);
+						}
+					} else {
+						const float2 v = make_float2(acc[im][0][r] + bv, acc[im][1][r] + bv);
+						*reinterpret_cast<float2*>(cbase + o) = v;
+						if (p.g_out2) {
+							const float2 a2 = *reinterpret_cast<const float2*>(p.g_add + img_off + o);
+							*reinterpret_cast<float2*>(p.g_out2 + img_off + o) = make_float2(v.x + a2.x, v.y + a2.y);
+						}
+					}
 				}
 			return;
 		}
@@ -1568,6 +1588,7 @@ int gather3_splits(int M, int N, int K) {
 	const long per = (slabs + splits - 1) / splits;
 	return (int)((slabs + per - 1) / per);
 }
+bool gather3_fuses_epilogue(int M, int N, int K) { return gather_hs(3, M, N) && gather3_splits(M, N, K) == 1; }
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 	if (mode != 2 && mode != 4) return 1;
 	const long K = (long)batch * HWo;
@@ -1576,7 +1597,7 @@ int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 }
 
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
-                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride) {
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep) {
 	BLA_REQUIRE(mode >= 1 && mode <= 4, BLA_ERR_INVALID, "gather mode %d", mode);
 	BLA_REQUIRE(mode != 3 || (N % 4 == 0 && HWo % 4 == 0 && N >= 4), BLA_ERR_INVALID, "mode 3 needs pixel counts that are multiples of 4");
 	BLA_REQUIRE(mode != 4 || M % 4 == 0, BLA_ERR_INVALID, "mode 4 needs a tap count that is a multiple of 4");
@@ -1603,6 +1624,10 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
 	// whole tiles: the half-slab pipeline (fragment sets per k-half, every LDS read and DMA dealt out between MFMAs) -- BLA_CONV_HS=0 keeps the older form
 	const bool hs = gather_hs(mode, M, N);
+	if (ep && (ep->bias || ep->out2)) {
+		BLA_REQUIRE(mode == 3 && hs && splits == 1, BLA_ERR_INVALID, "the fused convolution epilogue needs the half-slab forward kernel in one pass over K (gather3_fuses_epilogue)");
+		a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2;
+	}
 	if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
 	else if (hs) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true>), grid, block, lds_bytes, s, a);
 	else if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);

@@ -43,8 +43,10 @@ inline const float* zero_word() { return reinterpret_cast<const float*>(ctx().ti
 // tables: {element offset, y | x << 16}.  Needs K % 16 == 0 (mode 2: HWo % 16 == 0), A 16-byte aligned with lda % 4 == 0.
 int gather3_splits(int M, int N, int K);                               // ... of a mode-3 product (forward / data gradient on few tiles)
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo);   // K splits (= slabs of M*N floats in the workspace) gather_gemm will use
+struct GatherEpilogue { const float* bias; int bias_stride; const float* add; float* out2; };   // mode 3: out = product + bias[image * stride + row]; out2 = out + add
+bool gather3_fuses_epilogue(int M, int N, int K);                      // true: gather_gemm(mode 3, ...) takes a GatherEpilogue
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
-                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride);
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep = nullptr);
 
 // bla_conv.hip: implicit-GEMM convolution with the adds the U-Net puts behind it: out = conv + ep_bias[image * ep_bias_stride + channel];
 // ep_out2 = out + ep_add, both optional.  One image: folded into the store; a batch: one pass behind the product.
