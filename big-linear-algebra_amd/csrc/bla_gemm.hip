@@ -283,13 +283,18 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 
 // (Forcing 3 workgroups per CU through __launch_bounds__ -- 167 VGPRs, accumulators out of the AGPRs -- was measured
 // at 100 vs 141 TFLOP/s on 4096^3: two resident workgroups with AGPR accumulators is the operating point.)
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false>
-__global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
+// WK > 1: WK groups of WM x WN waves; group g multiplies k-parts [g KK/WK, (g+1) KK/WK) of every slab for the WHOLE tile, the groups' accumulators
+// meet in LDS after the K loop (group order).  Two waves per SIMD on a tile that would otherwise give every SIMD one wave with one accumulator
+// block (64x64: a lone wave's waits and barrier skew leave the matrix pipe idle).
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false,
+          int WK = 1>
+__global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
 	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && BN == 128 && BK == 16 && WM * WN == 4),
 	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image, mode 4 gathers A and takes a K-contiguous B");
-	constexpr int NW = WM * WN;
+	constexpr int NW = WM * WN * WK;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8;
+	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8, KKW = KK / WK;   // KKW: k-parts of a slab this wave multiplies
+	static_assert(WK == 1 || (KK % WK == 0 && NBUF == 2 && !PERSIST && GATHER == 0 && !HS && !(TM == 4 && TN == 4)), "waves along K: the plain two-buffer pipeline only");
 	typedef KcImage<BM, BK> AI;
 	typedef KcImage<BN, BK> BI;
 	extern __shared__ __attribute__((aligned(16))) float lds[];  // [NBUF][A_SZ + B_SZ], all LDS in this one array
@@ -297,7 +302,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int l31 = lane & 31, h = lane >> 5;
-	const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+	const int wk = wave / (WM * WN), wsp = wave % (WM * WN);   // group along K, position in the tile
+	const int wm0 = (wsp / WN) * (BM / WM), wn0 = (wsp % WN) * (BN / WN);
 
 	// virtual block id -> tile origin: XCD remap, then groups of 8 tile-rows walked column by column
 	auto tile_origin = [&](int vb, int& tm0, int& tn0) {
@@ -552,16 +558,16 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	//                                                     s_waitcnt vmcnt(0) before any ds_read that follows an LDS-DMA)
 	//             [remaining MFMA groups of slab kt from P]
 	// so a wave's MFMA stream only pauses for the barrier skew, never for LDS or HBM latency.
-	auto mfma_group = [&](float (&a)[KK][TM][4], float (&b)[KK][TN][4], int kk, int j) {
+	auto mfma_group = [&](float (&a)[KKW][TM][4], float (&b)[KKW][TN][4], int kk, int j) {
 #pragma unroll
 		for (int im = 0; im < TM; im++)
 #pragma unroll
 			for (int in = 0; in < TN; in++)
 				acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][im][j], b[kk][in][j], acc[im][in], 0, 0, 0);
 	};
-	auto rest = [&](float (&pa)[KK][TM][4], float (&pb)[KK][TN][4]) {
+	auto rest = [&](float (&pa)[KKW][TM][4], float (&pb)[KKW][TN][4]) {
 #pragma unroll
-		for (int kk = 0; kk < KK; kk++)
+		for (int kk = 0; kk < KKW; kk++)
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 				if (kk != 0 || j != 0) mfma_group(pa, pb, kk, j);
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	auto dma_one = [&](int, int) {};
 	auto dma_advance = [&](bool) {};
 #endif
-	auto step = [&](int kt, bool do_dma, float (&pa)[KK][TM][4], float (&pb)[KK][TN][4], float (&qa)[KK][TM][4], float (&qb)[KK][TN][4]) {
+	auto step = [&](int kt, bool do_dma, float (&pa)[KKW][TM][4], float (&pb)[KKW][TN][4], float (&qa)[KKW][TM][4], float (&qb)[KKW][TN][4]) {
 		// sched_barrier(0) pins the order: hipcc otherwise floats the MFMAs (which touch no memory) across the
 		// barrier and the waits, e.g. hoisting the NEXT step's vmcnt(0)+barrier above this step's MFMAs.
 		mfma_group(pa, pb, 0, 0);
@@ -662,7 +668,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 		__builtin_amdgcn_s_barrier();
 		const float* As = lds + ((kt + 1) & 1) * (A_SZ + B_SZ);
 #pragma unroll
-		for (int kk = 0; kk < KK; kk++) frags(As, As + A_SZ, kk, qa[kk], qb[kk]);
+		for (int kk = 0; kk < KKW; kk++) frags(As, As + A_SZ, wk * KKW + kk, qa[kk], qb[kk]);
 		if (do_dma) dma(kt & 1);
 		__builtin_amdgcn_sched_barrier(0);
 		rest(pa, pb);
@@ -1080,13 +1086,13 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	} else {
-	float fa0[KK][TM][4], fb0[KK][TN][4], fa1[KK][TM][4], fb1[KK][TN][4];
+	float fa0[KKW][TM][4], fb0[KKW][TN][4], fa1[KKW][TM][4], fb1[KKW][TN][4];
 	if (nkt > 0) {
 		dma(0);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 #pragma unroll
-		for (int kk = 0; kk < KK; kk++) frags(lds, lds + A_SZ, kk, fa0[kk], fb0[kk]);
+		for (int kk = 0; kk < KKW; kk++) frags(lds, lds + A_SZ, wk * KKW + kk, fa0[kk], fb0[kk]);
 		if (nkt > 1) dma(1);
 		int kt = 0;
 		for (; kt + 2 < nkt; kt += 2) {
@@ -1104,6 +1110,32 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) gemm_f32_glds_kernel(GemmA
 	}
 	}   // NBUF == 2
 
+	if constexpr (WK > 1) {   // the groups' partial tiles meet in LDS (the slab buffers are free now), summed in group order
+		constexpr int PER = TM * TN * 16 * 64;   // floats of one wave's accumulators, [block][register][lane]
+		static_assert((WK - 1) * WM * WN * PER <= NBUF * (A_SZ + B_SZ), "the partial tiles must fit the slab buffers");
+		__syncthreads();
+		if (wk > 0) {
+			float* mine = lds + ((wk - 1) * (WM * WN) + wsp) * PER;
+#pragma unroll
+			for (int i = 0; i < TM; i++)
+#pragma unroll
+				for (int j = 0; j < TN; j++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) mine[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+		}
+		__syncthreads();
+		if (wk > 0) return;
+#pragma unroll
+		for (int g = 1; g < WK; g++) {
+			const float* theirs = lds + ((g - 1) * (WM * WN) + wsp) * PER;
+#pragma unroll
+			for (int i = 0; i < TM; i++)
+#pragma unroll
+				for (int j = 0; j < TN; j++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) acc[i][j][r] += theirs[((i * TN + j) * 16 + r) * 64 + lane];
+		}
+	}
 	if constexpr (!PERSIST) store_tile();
 }
 
@@ -1471,6 +1503,7 @@ static const Config kConfigs[] = {
 	{128, 256, 16, 256, true, "glds128x256x16h"},   // ... and on 128x256 (waves 2x2, each 64x128): +8 % on 128 x 1152 x 65536, behind elsewhere
 	{16, 16, 16, 256, false, "wsk16x16"},       // wave-split-K on 16x16 tiles (MFMA 16x16x4): forced form of what config 6 picks by itself for few tiles
 	{192, 192, 16, 256, true, "glds192x192x16h"},   // the half-slab pipeline on 192x192 (waves 2x2, each 96x96 = 3x3 blocks): 3072^2 is exactly 256 of them
+	{64, 64, 32, 512, true, "glds64x64x32k2"},      // 64x64 tiles, 32-deep slabs, two groups of 2x2 waves along K (two waves per SIMD on a one-tile-per-CU problem: 1024^3)
 };
 static constexpr int kCfgHs192 = 17;
 static constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
@@ -1512,13 +1545,13 @@ static hipError_t launch_variant(const GemmArgs& a, bool akc, bool bkc, int mode
 #undef BLA_LAUNCH
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bool PERSIST = false, bool HS = false>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, int NBUF = 2, bool PERSIST = false, bool HS = false, int WK = 1>
 static hipError_t launch_glds(const GemmArgs& a, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 	size_t lds_bytes = NBUF * (BM + BN) * BK * sizeof(float);
-	dim3 block(WM * WN * 64);
+	dim3 block(WM * WN * WK * 64);
 #define BLA_LAUNCH2(AK, BK_, RG)                                                                            \
 	do {                                                                                                    \
-		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST, 0, RG, HS>;      \
+		auto kern = gemm_f32_glds_kernel<BM, BN, BK, WM, WN, AK, BK_, MINW, NBUF, PERSIST, 0, RG, HS, WK>;  \
 		if (lds_bytes > 48 * 1024) {                                                                        \
 			hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			if (e != hipSuccess) return e;                                                                  \
@@ -1723,22 +1756,26 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
 			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
 			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
-			const int cand[7] = {3, 7, 4, 11, 13, 14, kCfgHs192};
-			const double eff[7] = {1.0, 0.95, 0.87, 1.03, 1.03, 1.0, 1.03};
+			const int cand[8] = {3, 7, 4, 11, 13, 14, kCfgHs192, 18};
+			const double eff[8] = {1.0, 0.95, 0.87, 1.03, 1.03, 1.0, 1.03, 0.93};
 			// Half-slab pipeline (configs 11, 13, 14, 17): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C
 			// only.  The tile is picked so that the tile count is a whole number of rounds over the CUs: 4096^2 = 256 tiles of 256x256, 3072^2 = 256
 			// of 192x192 (147.6 TFLOP/s against 128 on 64x64 tiles), 2048^2 = 256 of 128x128 (134.6 against 125.7 on 128x64).
 			const bool big_ok = k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
 			                    !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !a.row_sum_a;
 			double best = 0;
-			for (int i = 0; i < 7; i++) {
+			for (int i = 0; i < 8; i++) {
 				const Config& cc = kConfigs[cand[i]];
-				if (i >= 3 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;
+				if (i >= 3 && i < 7 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;
 				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
+				// 64x64 tiles with two wave groups along K (config 18): the small problems where a CU holds one or two tiles (1024^3: 19.8 against 20.6 us,
+				// 1280^3: 41.9 against 45.3, 1536^3: 71 against 77); needs whole 32-deep slabs
+				if (i == 7 && !(k % 32 == 0 && t <= 3L * cus)) continue;
 				long rounds = (t + cus - 1) / cus;
 				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
-				if (t < 2L * cus && i < 3) cost /= 0.88;
-				if (i >= 3 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
+				if (t < 2L * cus && (i < 3 || i == 7)) cost /= 0.88;
+				if (t < cus && i < 3) cost *= 1.25;   // ... and will have its K cut over workgroups: slabs and a fold launch (1280^3 on 128x64 tiles: 51 us)
+				if (i >= 3 && i < 7 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
 				if (i == 0 || cost < best) { best = cost; cfg = cand[i]; }
 			}
 		}
@@ -1874,6 +1911,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 		case 13: e = launch_glds<128, 512, 16, 1, 4>(a, akc, bkc, grid, s); break;
 		case 14: e = launch_glds<128, 128, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;
 		case 15: e = launch_glds<128, 256, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;
+		case 18: e = launch_glds<64, 64, 32, 2, 2, 1, 2, false, false, 2>(a, akc, bkc, grid, s); break;
 		default: e = launch_glds<192, 192, 16, 2, 2, 1, 2, false, true>(a, akc, bkc, grid, s); break;   // 17
 	}
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_kernel launch");

@@ -60,7 +60,7 @@ def test_golden_random_shapes(dev, ora):
         check_gemm(ora, run(dev, a, b), a, b, g[f"rand{i}_c"], f"rand{i} {m}x{k}x{n}")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     """Every transpose combination on every tile configuration, sizes straddling tile edges.
@@ -75,7 +75,7 @@ def test_all_layouts_and_tiles(dev, ora, cfg, ta, tb):
     if 3 <= cfg <= 5 or cfg >= 7:
         shapes = [(4, 32, 4), (64, 32, 64), (68, 64, 60), (132, 96, 128), (128, 128, 128), (260, 160, 36), (200, 256, 136),
                   (384, 512, 256), (516, 16, 260), (300, 48, 520), (256, 80, 128), (132, 112, 140), (128, 144, 128)]
-        if cfg in (5, 10):   # BK = 32, or the persistent kernel's even slab count
+        if cfg in (5, 10, 18):   # BK = 32, or the persistent kernel's even slab count
             shapes = [s for s in shapes if s[1] % 32 == 0]
         if cfg == 11:        # 256x256 tiles, whole tiles only
             shapes = [(256, 32, 256), (512, 48, 256), (256, 160, 768), (512, 512, 512)]
