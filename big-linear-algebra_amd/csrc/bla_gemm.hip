@@ -1588,13 +1588,14 @@ static hipError_t launch_wsk(const GemmArgs& a, bool akc, bool bkc, bool avec, b
 
 // K splits of a gathered weight-gradient product (contraction over (image, pixel), K = batch * HWo, few output tiles).  The tiles are MFMA-bound
 // and equally long, so what matters is that every CU gets the SAME number of workgroups: tiles * splits is rounded DOWN to a whole number of
-// workgroups per CU (one on the half-slab kernel, which holds one workgroup per CU; two on the older form) -- 9 tiles x 32 splits on 256 CUs
+// workgroups per CU (two) -- 9 tiles x 32 splits on 256 CUs
 // left 32 CUs with two workgroups and took twice the time of 9 x 28.  A split is a whole number of 16-deep slabs, not of images.
 static bool gather_hs(int mode, int M, int N) {
 	static const bool use_hs = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '0'); }();
-	// mode 3 (forward / data gradient): the half-slab form (172 vs 198 us at 128->128 @32x32 x64); mode 4 (weight gradient) measured slower on it
-	// (208 vs 191 us: its one workgroup per CU against two of the older form), BLA_CONV_HS=2 forces it there too
-	static const bool hs4 = [] { const char* e = getenv("BLA_CONV_HS"); return e && e[0] == '2'; }();
+	// mode 3 (forward / data gradient): the half-slab form (172 vs 198 us at 128->128 @32x32 x64).  Mode 4 (weight gradient): also, with its K cut for
+	// TWO workgroups per CU (they fit: 32 KB of LDS, under half the registers) -- 183 against 191 us on the older form; cut for one per CU it
+	// measured slower (208).  BLA_CONV_HS=1 keeps the weight gradient on the older form, BLA_CONV_HS=0 everything.
+	static const bool hs4 = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '1'); }();
 	return use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || (mode == 4 && hs4));
 }
 static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
@@ -1602,7 +1603,7 @@ static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
 	if (mode != 2 && mode != 4) return (int)K;
 	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
 	const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-	const long slots = (gather_hs(mode, M, N) ? 1L : 2L) * cus;
+	const long slots = 2L * cus;   // two workgroups per CU on either form
 	long splits = slots / tiles;
 	const long slabs = K / 16;
 	if (splits > slabs / 8) splits = slabs / 8;      // at least 8 slabs per split
