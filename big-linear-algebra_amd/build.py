@@ -91,7 +91,8 @@ def build_host(force=False):
     if force or _newer(HOST_SO, srcs + hdrs + [HIP_SO]):
         _run(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-o", HOST_SO] + srcs +
              ["-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}", "-lm"])
-    f64_srcs = [os.path.join(HOST, f) for f in ("matrix.c", "bla_host.c", "csv.c", "mnist_csv2.c")]
+    # -DBLA_FP64: matrix.h, conv.h, norm.h, util.h and the readers in the reference's own element type (layer.h's float* callbacks do not fit it)
+    f64_srcs = [os.path.join(HOST, f) for f in ("matrix.c", "conv.c", "norm.c", "util.c", "bla_host.c", "csv.c", "mnist_csv2.c", "cifar10.c", "bmp.c")]
     if force or _newer(HOST_F64_SO, f64_srcs + hdrs + [HIP_SO]):
         _run(["gcc", "-std=c99", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-DBLA_FP64", "-I", INCLUDE, "-o", HOST_F64_SO] + f64_srcs +
              ["-L", CSRC, "-l:libbla_hip.so", f"-Wl,-rpath,{CSRC}", "-lm"])

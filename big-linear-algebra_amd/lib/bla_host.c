@@ -65,23 +65,23 @@ float* bla_host_pack_block(int which, size_t floats) {
 	return g_pack[which];
 }
 
-#ifndef BLA_FP64   /* the channel-array helpers serve conv.h / norm.h, which exist in fp32 only */
+/* channel arrays (conv.h / norm.h): `count` equally sized Matrix planes of matrix_float_t <-> one contiguous device buffer */
+#define PLANE_WORDS(n) ((size_t)(n) * (sizeof(matrix_float_t) / sizeof(float)))
 float* bla_host_up_planes(int slot, Matrix* ch, int count) {
 	const size_t per = (size_t)ch[0].rows * ch[0].cols;
 	int contiguous = 1;
 	for (int c = 1; c < count && contiguous; c++) contiguous = ch[c].data == ch[0].data + c * per;
-	if (contiguous) return bla_host_up(slot, ch[0].data, per * count);
-	float* block = bla_host_pack_block(0, per * count);
-	for (int c = 0; c < count; c++) memcpy(block + c * per, ch[c].data, per * sizeof(float));
-	float* d = bla_host_up(slot, block, per * count);
+	if (contiguous) return bla_host_up(slot, (const float*)ch[0].data, PLANE_WORDS(per * count));
+	matrix_float_t* block = (matrix_float_t*)bla_host_pack_block(0, PLANE_WORDS(per * count));
+	for (int c = 0; c < count; c++) memcpy(block + c * per, ch[c].data, per * sizeof(matrix_float_t));
+	float* d = bla_host_up(slot, (const float*)block, PLANE_WORDS(per * count));
 	BLA_TRY(bla_stream_sync(NULL));       /* the block is reused by the next operand */
 	return d;
 }
 
 void bla_host_down_planes(Matrix* ch, int count, const float* d) {
 	const size_t per = (size_t)ch[0].rows * ch[0].cols;
-	float* block = bla_host_pack_block(1, per * count);
-	bla_host_down(block, d, per * count);
-	for (int c = 0; c < count; c++) memcpy(ch[c].data, block + c * per, per * sizeof(float));
+	matrix_float_t* block = (matrix_float_t*)bla_host_pack_block(1, PLANE_WORDS(per * count));
+	bla_host_down((float*)block, d, PLANE_WORDS(per * count));
+	for (int c = 0; c < count; c++) memcpy(ch[c].data, block + c * per, per * sizeof(matrix_float_t));
 }
-#endif

@@ -16,7 +16,7 @@
  *    intended gradient (the adjoint of _im2col); BLA_STRICT_REFERENCE=1 refuses instead.
  */
 #include "conv.h"
-#include "bla_host.h"
+#include "bla_dev.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,79 +24,79 @@
 enum { S_X = 3, S_KERN, S_IM2COL, S_KMAT, S_PRODUCT, S_OUTPUT, S_AUX0, S_AUX1, S_AUX2 };
 
 /* channel arrays travel as one copy per operand (bla_host_up_planes / bla_host_down_planes); kernel sets [F][C] likewise */
-#define up_channels bla_host_up_planes
-#define down_channels bla_host_down_planes
+#define up_channels dev_up_planes
+#define down_channels dev_down_planes
 
-static float* up_kernels(int slot, Matrix** kernels, int f_n, int c_n) {
+static bla_elem_t* up_kernels(int slot, Matrix** kernels, int f_n, int c_n) {
 	const size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
-	float* block = bla_host_pack_block(0, per * c_n * f_n);
+	matrix_float_t* block = (matrix_float_t*)bla_host_pack_block(0, WORDS(per * c_n * f_n));
 	for (int f = 0; f < f_n; f++)
-		for (int c = 0; c < c_n; c++) memcpy(block + ((size_t)f * c_n + c) * per, kernels[f][c].data, per * sizeof(float));
-	float* d = bla_host_up(slot, block, per * c_n * f_n);
+		for (int c = 0; c < c_n; c++) memcpy(block + ((size_t)f * c_n + c) * per, kernels[f][c].data, per * sizeof(matrix_float_t));
+	bla_elem_t* d = dev_up(slot, block, per * c_n * f_n);
 	BLA_TRY(bla_stream_sync(NULL));
 	return d;
 }
 
-static void down_kernels(Matrix** kernels, int f_n, int c_n, const float* d) {
+static void down_kernels(Matrix** kernels, int f_n, int c_n, const bla_elem_t* d) {
 	const size_t per = (size_t)kernels[0][0].rows * kernels[0][0].cols;
-	float* block = bla_host_pack_block(1, per * c_n * f_n);
-	bla_host_down(block, d, per * c_n * f_n);
+	matrix_float_t* block = (matrix_float_t*)bla_host_pack_block(1, WORDS(per * c_n * f_n));
+	dev_down(block, d, per * c_n * f_n);
 	for (int f = 0; f < f_n; f++)
-		for (int c = 0; c < c_n; c++) memcpy(kernels[f][c].data, block + ((size_t)f * c_n + c) * per, per * sizeof(float));
+		for (int c = 0; c < c_n; c++) memcpy(kernels[f][c].data, block + ((size_t)f * c_n + c) * per, per * sizeof(matrix_float_t));
 }
 
 /* reference lib/conv.c:8-77 */
 void _im2col(Matrix* in, Matrix* out, int kernel_size, int in_channels, int stride) {
-	float* dx = up_channels(S_X, in, in_channels);
+	bla_elem_t* dx = up_channels(S_X, in, in_channels);
 	size_t n = (size_t)out->rows * out->cols;
-	float* dout = bla_host_buf(S_IM2COL, n);
-	BLA_TRY(bla_im2col_f32(NULL, dx, dout, in[0].rows, in[0].cols, kernel_size, in_channels, stride));
-	bla_host_down(out->data, dout, n);
+	bla_elem_t* dout = dev_buf(S_IM2COL, n);
+	BLA_TRY(DEV(im2col)(NULL, dx, dout, in[0].rows, in[0].cols, kernel_size, in_channels, stride));
+	dev_down(out->data, dout, n);
 }
 
 /* reference lib/conv.c:80-135 (defined for stride 1; other strides: the adjoint of _im2col, refused under BLA_STRICT_REFERENCE=1) */
 void _col2im(Matrix* in, Matrix* out, int kernel_size, int out_channels, int stride) {
-	float* dcols = bla_host_up(S_IM2COL, in->data, (size_t)in->rows * in->cols);
-	float* dout = bla_host_buf(S_X, (size_t)out[0].rows * out[0].cols * out_channels);
-	BLA_TRY(bla_col2im_f32(NULL, dcols, dout, out[0].rows, out[0].cols, kernel_size, out_channels, stride));
+	bla_elem_t* dcols = dev_up(S_IM2COL, in->data, (size_t)in->rows * in->cols);
+	bla_elem_t* dout = dev_buf(S_X, (size_t)out[0].rows * out[0].cols * out_channels);
+	BLA_TRY(DEV(col2im)(NULL, dcols, dout, out[0].rows, out[0].cols, kernel_size, out_channels, stride));
 	down_channels(out, out_channels, dout);
 }
 
 /* reference lib/conv.c:138-153: sizes are derived exactly as there (k from kernels[0][0].rows, F = matrix->cols) */
 void _reshape_kernels_matrix(Matrix** kernels, Matrix* matrix) {
 	int k = kernels[0][0].rows, f_n = matrix->cols, c_n = matrix->rows / (k * k);
-	float* dk = up_kernels(S_KERN, kernels, f_n, c_n);
+	bla_elem_t* dk = up_kernels(S_KERN, kernels, f_n, c_n);
 	size_t n = (size_t)matrix->rows * matrix->cols;
-	float* dm = bla_host_buf(S_KMAT, n);
-	BLA_TRY(bla_kernels_to_matrix_f32(NULL, dk, dm, f_n, c_n, k));
-	bla_host_down(matrix->data, dm, n);
+	bla_elem_t* dm = dev_buf(S_KMAT, n);
+	BLA_TRY(DEV(kernels_to_matrix)(NULL, dk, dm, f_n, c_n, k));
+	dev_down(matrix->data, dm, n);
 }
 
 /* reference lib/conv.c:156-171 */
 void _reshape_matrix_kernels(Matrix* matrix, Matrix** kernels) {
 	int k = kernels[0][0].rows, f_n = matrix->cols, c_n = matrix->rows / (k * k);
-	float* dm = bla_host_up(S_KMAT, matrix->data, (size_t)matrix->rows * matrix->cols);
-	float* dk = bla_host_buf(S_KERN, (size_t)f_n * c_n * k * k);
-	BLA_TRY(bla_matrix_to_kernels_f32(NULL, dm, dk, f_n, c_n, k));
+	bla_elem_t* dm = dev_up(S_KMAT, matrix->data, (size_t)matrix->rows * matrix->cols);
+	bla_elem_t* dk = dev_buf(S_KERN, (size_t)f_n * c_n * k * k);
+	BLA_TRY(DEV(matrix_to_kernels)(NULL, dm, dk, f_n, c_n, k));
 	down_kernels(kernels, f_n, c_n, dk);
 }
 
 /* reference lib/conv.c:174-187, direction as written: channels[c][idx] = matrix[idx*C + c] */
 void reshape_channels_matrix(Matrix* channels, Matrix* matrix) {
 	int c_n = matrix->cols, hw = channels[0].rows * channels[0].cols;
-	float* dm = bla_host_up(S_PRODUCT, matrix->data, (size_t)hw * c_n);
-	float* dc = bla_host_buf(S_OUTPUT, (size_t)hw * c_n);
-	BLA_TRY(bla_reshape_channels_matrix_f32(NULL, dc, dm, c_n, hw));
+	bla_elem_t* dm = dev_up(S_PRODUCT, matrix->data, (size_t)hw * c_n);
+	bla_elem_t* dc = dev_buf(S_OUTPUT, (size_t)hw * c_n);
+	BLA_TRY(DEV(reshape_channels_matrix)(NULL, dc, dm, c_n, hw));
 	down_channels(channels, c_n, dc);
 }
 
 /* reference lib/conv.c:190-203, direction as written: matrix[idx*C + c] = channels[c][idx] */
 void reshape_matrix_channels(Matrix* matrix, Matrix* channels) {
 	int c_n = matrix->cols, hw = channels[0].rows * channels[0].cols;
-	float* dc = up_channels(S_OUTPUT, channels, c_n);
-	float* dm = bla_host_buf(S_PRODUCT, (size_t)hw * c_n);
-	BLA_TRY(bla_reshape_matrix_channels_f32(NULL, dm, dc, c_n, hw));
-	bla_host_down(matrix->data, dm, (size_t)hw * c_n);
+	bla_elem_t* dc = up_channels(S_OUTPUT, channels, c_n);
+	bla_elem_t* dm = dev_buf(S_PRODUCT, (size_t)hw * c_n);
+	BLA_TRY(DEV(reshape_matrix_channels)(NULL, dm, dc, c_n, hw));
+	dev_down(matrix->data, dm, (size_t)hw * c_n);
 }
 
 /* reference lib/conv.c:205-212.  X: in_channels matrices H x W; kernels[f][c]: k x k. */
@@ -107,24 +107,24 @@ void conv(Matrix* X, Matrix** kernels, ConvData* data, int in_channels, int out_
 	int ho, wo;
 	BLA_TRY(bla_conv_out_hw(h, w, stride, &ho, &wo));
 	const size_t hw = (size_t)ho * wo, kkc = (size_t)k * k * in_channels;
-	float* dx = up_channels(S_X, X, in_channels);
-	float* dk = up_kernels(S_KERN, kernels, f_n, in_channels);
-	float* dim = bla_host_buf(S_IM2COL, hw * kkc);
-	float* dkm = bla_host_buf(S_KMAT, kkc * f_n);
-	float* dpr = bla_host_buf(S_PRODUCT, hw * f_n);
-	float* dout = bla_host_buf(S_OUTPUT, hw * f_n);
+	bla_elem_t* dx = up_channels(S_X, X, in_channels);
+	bla_elem_t* dk = up_kernels(S_KERN, kernels, f_n, in_channels);
+	bla_elem_t* dim = dev_buf(S_IM2COL, hw * kkc);
+	bla_elem_t* dkm = dev_buf(S_KMAT, kkc * f_n);
+	bla_elem_t* dpr = dev_buf(S_PRODUCT, hw * f_n);
+	bla_elem_t* dout = dev_buf(S_OUTPUT, hw * f_n);
 	if (!bla_host_strict()) {
-		BLA_TRY(bla_conv_forward_f32(NULL, dx, dk, dim, dkm, dpr, dout, h, w, k, in_channels, f_n, stride));
-		bla_host_down(data->im2col->data, dim, hw * kkc);
-		bla_host_down(data->kernel_matrix->data, dkm, kkc * f_n);
-		bla_host_down(data->product->data, dpr, hw * f_n);
+		BLA_TRY(DEV(conv_forward)(NULL, dx, dk, dim, dkm, dpr, dout, h, w, k, in_channels, f_n, stride));
+		dev_down(data->im2col->data, dim, hw * kkc);
+		dev_down(data->kernel_matrix->data, dkm, kkc * f_n);
+		dev_down(data->product->data, dpr, hw * f_n);
 		down_channels(data->output, f_n, dout);
 	} else {
 		/* literal reference: im2col, kernel reshape, product ... then product <- stale output (lib/conv.c:211) */
-		BLA_TRY(bla_im2col_f32(NULL, dx, dim, h, w, k, in_channels, stride));
-		BLA_TRY(bla_kernels_to_matrix_f32(NULL, dk, dkm, f_n, in_channels, k));
-		bla_host_down(data->im2col->data, dim, hw * kkc);
-		bla_host_down(data->kernel_matrix->data, dkm, kkc * f_n);
+		BLA_TRY(DEV(im2col)(NULL, dx, dim, h, w, k, in_channels, stride));
+		BLA_TRY(DEV(kernels_to_matrix)(NULL, dk, dkm, f_n, in_channels, k));
+		dev_down(data->im2col->data, dim, hw * kkc);
+		dev_down(data->kernel_matrix->data, dkm, kkc * f_n);
 		reshape_matrix_channels(data->product, data->output);
 	}
 }
@@ -145,23 +145,23 @@ void conv_ddx(Matrix* del_Y, ConvData* data, ConvData* grad_data, Matrix** del_k
 		fprintf(stderr, "conv_ddx: stride %d is undefined in the reference (_col2im is only valid for stride 1, lib/conv.c:80-135)\n", stride);
 		exit(1);
 	}
-	float* ddy;
+	bla_elem_t* ddy;
 	if (bla_host_strict()) {
 		/* literal first step (lib/conv.c:220): del_Y is overwritten from the stale del_Q */
 		reshape_channels_matrix(del_Y, grad_data->product);
 	}
 	ddy = up_channels(S_OUTPUT, del_Y, f_n);
-	float* dim = bla_host_up(S_IM2COL, data->im2col->data, hw * kkc);
-	float* dkm = bla_host_up(S_KMAT, data->kernel_matrix->data, kkc * f_n);
-	float* ddq = bla_host_buf(S_PRODUCT, hw * f_n);
-	float* ddkm = bla_host_buf(S_AUX0, kkc * f_n);
-	float* ddk = bla_host_buf(S_KERN, kkc * f_n);
-	float* ddcol = bla_host_buf(S_AUX1, hw * kkc);
-	float* ddx = bla_host_buf(S_X, (size_t)h * w * in_channels);
-	BLA_TRY(bla_conv_backward_f32(NULL, ddy, dim, dkm, ddq, ddkm, ddk, ddcol, ddx, h, w, k, in_channels, f_n, stride));
-	if (!bla_host_strict()) bla_host_down(grad_data->product->data, ddq, hw * f_n);   /* strict: del_Q is left as it was */
-	bla_host_down(grad_data->kernel_matrix->data, ddkm, kkc * f_n);
-	bla_host_down(grad_data->im2col->data, ddcol, hw * kkc);
+	bla_elem_t* dim = dev_up(S_IM2COL, data->im2col->data, hw * kkc);
+	bla_elem_t* dkm = dev_up(S_KMAT, data->kernel_matrix->data, kkc * f_n);
+	bla_elem_t* ddq = dev_buf(S_PRODUCT, hw * f_n);
+	bla_elem_t* ddkm = dev_buf(S_AUX0, kkc * f_n);
+	bla_elem_t* ddk = dev_buf(S_KERN, kkc * f_n);
+	bla_elem_t* ddcol = dev_buf(S_AUX1, hw * kkc);
+	bla_elem_t* ddx = dev_buf(S_X, (size_t)h * w * in_channels);
+	BLA_TRY(DEV(conv_backward)(NULL, ddy, dim, dkm, ddq, ddkm, ddk, ddcol, ddx, h, w, k, in_channels, f_n, stride));
+	if (!bla_host_strict()) dev_down(grad_data->product->data, ddq, hw * f_n);   /* strict: del_Q is left as it was */
+	dev_down(grad_data->kernel_matrix->data, ddkm, kkc * f_n);
+	dev_down(grad_data->im2col->data, ddcol, hw * kkc);
 	down_kernels(del_kernels, f_n, in_channels, ddk);
 	down_channels(del_input, in_channels, ddx);
 }

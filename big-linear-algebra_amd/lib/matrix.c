@@ -11,17 +11,17 @@
 /* Element type on the device = matrix_float_t: float by default, double under -DBLA_FP64 (the reference's own type, lib/matrix.h:4).  The
  * staging buffers of bla_host.c are counted in floats: WORDS() converts. */
 #ifdef BLA_FP64
-typedef double dev_t;
+typedef double bla_elem_t;
 #define DEV(name) bla_##name##_f64
 #else
-typedef float dev_t;
+typedef float bla_elem_t;
 #define DEV(name) bla_##name##_f32
 #endif
 #define WORDS(n) ((size_t)(n) * (sizeof(matrix_float_t) / sizeof(float)))
-static dev_t* up(int slot, const matrix_float_t* h, size_t n) { return (dev_t*)bla_host_up(slot, (const float*)h, WORDS(n)); }
-static dev_t* buf(int slot, size_t n) { return (dev_t*)bla_host_buf(slot, WORDS(n)); }
-static void down(matrix_float_t* h, const dev_t* d, size_t n) { bla_host_down((float*)h, (const float*)d, WORDS(n)); }
-static void dev_gemm(int m, int n, int k, const dev_t* a, const dev_t* b, dev_t* c) {
+static bla_elem_t* up(int slot, const matrix_float_t* h, size_t n) { return (bla_elem_t*)bla_host_up(slot, (const float*)h, WORDS(n)); }
+static bla_elem_t* buf(int slot, size_t n) { return (bla_elem_t*)bla_host_buf(slot, WORDS(n)); }
+static void down(matrix_float_t* h, const bla_elem_t* d, size_t n) { bla_host_down((float*)h, (const float*)d, WORDS(n)); }
+static void dev_gemm(int m, int n, int k, const bla_elem_t* a, const bla_elem_t* b, bla_elem_t* c) {
 #ifdef BLA_FP64
 	BLA_TRY(bla_gemm_f64(NULL, 0, 0, m, n, k, a, k, b, n, c, n, 1.0, 0.0));
 #else
@@ -71,24 +71,24 @@ struct Matrix* matrix_multiply(struct Matrix a, struct Matrix b) {
 void matrix_multiply_inplace(Matrix* a, Matrix* b, Matrix* c) {
 	const int m = a->rows, k = a->cols, n = b->cols;
 	if (m <= 0 || n <= 0) return;
-	dev_t* da = up(0, a->data, (size_t)m * k);
-	dev_t* db = up(1, b->data, (size_t)k * n);
-	dev_t* dc = buf(2, (size_t)m * n);
+	bla_elem_t* da = up(0, a->data, (size_t)m * k);
+	bla_elem_t* db = up(1, b->data, (size_t)k * n);
+	bla_elem_t* dc = buf(2, (size_t)m * n);
 	dev_gemm(m, n, k, da, db, dc);
 	down(c->data, dc, (size_t)m * n);
 }
 
 void matrix_scale(struct Matrix* m, matrix_float_t f) {          /* reference lib/matrix.c:59-63 */
 	size_t n = (size_t)m->rows * m->cols;
-	dev_t* d = up(0, m->data, n);
+	bla_elem_t* d = up(0, m->data, n);
 	BLA_TRY(DEV(scale)(NULL, d, n, f));
 	down(m->data, d, n);
 }
 
 void matrix_add(struct Matrix* a, struct Matrix* b) {            /* reference lib/matrix.c:65-69: a's size is trusted */
 	size_t n = (size_t)a->rows * a->cols;
-	dev_t* da = up(0, a->data, n);
-	dev_t* db = up(1, b->data, n);
+	bla_elem_t* da = up(0, a->data, n);
+	bla_elem_t* db = up(1, b->data, n);
 	BLA_TRY(DEV(add)(NULL, da, db, n));
 	down(a->data, da, n);
 }
@@ -114,8 +114,8 @@ void matrix_multiply_elementwise(struct Matrix* a, struct Matrix* b) {   /* refe
 		exit(1);
 	}
 	size_t n = (size_t)a->rows * a->cols;
-	dev_t* da = up(0, a->data, n);
-	dev_t* db = up(1, b->data, n);
+	bla_elem_t* da = up(0, a->data, n);
+	bla_elem_t* db = up(1, b->data, n);
 	BLA_TRY(DEV(hadamard)(NULL, da, db, n));
 	down(a->data, da, n);
 }
@@ -124,8 +124,8 @@ void matrix_multiply_elementwise(struct Matrix* a, struct Matrix* b) {   /* refe
 void matrix_transpose(struct Matrix* m) {
 	const int r = m->rows, c = m->cols;
 	size_t n = (size_t)r * c;
-	dev_t* din = up(0, m->data, n);
-	dev_t* dout = buf(1, n);
+	bla_elem_t* din = up(0, m->data, n);
+	bla_elem_t* dout = buf(1, n);
 	BLA_TRY(DEV(transpose)(NULL, din, dout, r, c));
 	down(m->data, dout, n);
 	m->rows = c;
@@ -135,8 +135,8 @@ void matrix_transpose(struct Matrix* m) {
 struct Matrix* matrix_row_sum(struct Matrix m) {                  /* reference lib/matrix.c:123-133 -> 1 x cols */
 	matrix_float_t* data = malloc((size_t)m.cols * sizeof(matrix_float_t));
 	struct Matrix* out = make_matrix(1, m.cols, data);
-	dev_t* d = up(0, m.data, (size_t)m.rows * m.cols);
-	dev_t* o = buf(1, (size_t)m.cols);
+	bla_elem_t* d = up(0, m.data, (size_t)m.rows * m.cols);
+	bla_elem_t* o = buf(1, (size_t)m.cols);
 	BLA_TRY(DEV(row_sum)(NULL, d, m.rows, m.cols, o));
 	down(data, o, (size_t)m.cols);
 	return out;
@@ -149,8 +149,8 @@ struct Matrix* matrix_row_sum(struct Matrix m) {                  /* reference l
 struct Matrix* matrix_col_sum(struct Matrix m) {
 	matrix_float_t* data = malloc((size_t)m.rows * sizeof(matrix_float_t));
 	struct Matrix* out = make_matrix(m.rows, 1, data);
-	dev_t* d = up(0, m.data, (size_t)m.rows * m.cols);
-	dev_t* o = buf(1, (size_t)m.rows);
+	bla_elem_t* d = up(0, m.data, (size_t)m.rows * m.cols);
+	bla_elem_t* o = buf(1, (size_t)m.rows);
 	int mode = m.rows <= m.cols ? BLA_COLSUM_AS_WRITTEN : BLA_COLSUM_INTENDED;
 	if (bla_host_strict()) mode = BLA_COLSUM_AS_WRITTEN;
 	BLA_TRY(DEV(col_sum)(NULL, d, m.rows, m.cols, o, mode));
@@ -158,10 +158,10 @@ struct Matrix* matrix_col_sum(struct Matrix m) {
 	return out;
 }
 
-static matrix_float_t reduce_scalar(struct Matrix m, bla_status (*fn)(void*, const dev_t*, size_t, dev_t*)) {
+static matrix_float_t reduce_scalar(struct Matrix m, bla_status (*fn)(void*, const bla_elem_t*, size_t, bla_elem_t*)) {
 	size_t n = (size_t)m.rows * m.cols;
-	dev_t* d = up(0, m.data, n);
-	dev_t* o = buf(1, 4);
+	bla_elem_t* d = up(0, m.data, n);
+	bla_elem_t* o = buf(1, 4);
 	BLA_TRY(fn(NULL, d, n, o));
 	matrix_float_t r;
 	down(&r, o, 1);
@@ -173,23 +173,23 @@ matrix_float_t max_value(struct Matrix m) { return reduce_scalar(m, DEV(max)); }
 
 void matrix_z_score_normalize(Matrix* m) {                        /* reference lib/matrix.c:170-185 */
 	size_t n = (size_t)m->rows * m->cols;
-	dev_t* d = up(0, m->data, n);
+	bla_elem_t* d = up(0, m->data, n);
 	BLA_TRY(DEV(zscore)(NULL, d, n));
 	down(m->data, d, n);
 }
 
 void matrix_add_tile_columns(struct Matrix* a, struct Matrix* b) {   /* reference lib/matrix.c:189-195 */
 	size_t n = (size_t)a->rows * a->cols;
-	dev_t* da = up(0, a->data, n);
-	dev_t* db = up(1, b->data, (size_t)a->rows * b->cols);
+	bla_elem_t* da = up(0, a->data, n);
+	bla_elem_t* db = up(1, b->data, (size_t)a->rows * b->cols);
 	BLA_TRY(DEV(add_tile_columns)(NULL, da, a->rows, a->cols, db, b->cols));
 	down(a->data, da, n);
 }
 
 void matrix_add_tile_rows(struct Matrix* a, struct Matrix* b) {      /* reference lib/matrix.c:199-205 */
 	size_t n = (size_t)a->rows * a->cols;
-	dev_t* da = up(0, a->data, n);
-	dev_t* db = up(1, b->data, (size_t)a->cols);
+	bla_elem_t* da = up(0, a->data, n);
+	bla_elem_t* db = up(1, b->data, (size_t)a->cols);
 	BLA_TRY(DEV(add_tile_rows)(NULL, da, a->rows, a->cols, db));
 	down(a->data, da, n);
 }

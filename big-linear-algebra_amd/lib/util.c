@@ -1,28 +1,28 @@
 /* util.c -- host side of the drop-in lib/util.h (reference lib/util.c).  Kept in its own object, as the
  * reference does, because model/mnist_nn.c defines its own relu/softmax/load_matrix_from_csv. */
 #include "util.h"
-#include "bla_host.h"
+#include "bla_dev.h"
 #include <math.h>
 #include <stdlib.h>
 
 void relu(matrix_float_t* data, int num) {                         /* reference lib/util.c:7-13 */
-	float* d = bla_host_up(0, data, (size_t)num);
-	BLA_TRY(bla_relu_f32(NULL, d, (size_t)num));
-	bla_host_down(data, d, (size_t)num);
+	bla_elem_t* d = dev_up(0, data, (size_t)num);
+	BLA_TRY(DEV(relu)(NULL, d, (size_t)num));
+	dev_down(data, d, (size_t)num);
 }
 
 void softmax(matrix_float_t* data, int rows, int cols) {            /* per column, reference lib/util.c:15-34 */
 	size_t n = (size_t)rows * cols;
-	float* d = bla_host_up(0, data, n);
-	BLA_TRY(bla_softmax_cols_f32(NULL, d, rows, cols));
-	bla_host_down(data, d, n);
+	bla_elem_t* d = dev_up(0, data, n);
+	BLA_TRY(DEV(softmax_cols)(NULL, d, rows, cols));
+	dev_down(data, d, n);
 }
 
 void softmax_row_wise(matrix_float_t* data, int rows, int cols) {   /* per row, reference lib/util.c:36-55 */
 	size_t n = (size_t)rows * cols;
-	float* d = bla_host_up(0, data, n);
-	BLA_TRY(bla_softmax_rows_f32(NULL, d, rows, cols));
-	bla_host_down(data, d, n);
+	bla_elem_t* d = dev_up(0, data, n);
+	BLA_TRY(DEV(softmax_rows)(NULL, d, rows, cols));
+	dev_down(data, d, n);
 }
 
 void load_matrix_from_csv(Matrix* m, const char* filepath, int rows, int cols) {   /* reference lib/util.c:57-65 */

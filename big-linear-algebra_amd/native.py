@@ -76,6 +76,12 @@ SIGNATURES = {
     "bla_add_tile_columns_f64": (_I, [_VP, _VP, _I, _I, _VP, _I]), "bla_add_tile_rows_f64": (_I, [_VP, _VP, _I, _I, _VP]),
     "bla_transpose_f64": (_I, [_VP, _VP, _VP, _I, _I]), "bla_row_sum_f64": (_I, [_VP, _VP, _I, _I, _VP]), "bla_col_sum_f64": (_I, [_VP, _VP, _I, _I, _VP, _I]),
     "bla_frobenius_f64": (_I, [_VP, _VP, _SZ, _VP]), "bla_max_f64": (_I, [_VP, _VP, _SZ, _VP]), "bla_zscore_f64": (_I, [_VP, _VP, _SZ]),
+    "bla_im2col_f64": (_I, [_VP, _VP, _VP] + [_I] * 5), "bla_col2im_f64": (_I, [_VP, _VP, _VP] + [_I] * 5),
+    "bla_kernels_to_matrix_f64": (_I, [_VP, _VP, _VP, _I, _I, _I]), "bla_matrix_to_kernels_f64": (_I, [_VP, _VP, _VP, _I, _I, _I]),
+    "bla_reshape_channels_matrix_f64": (_I, [_VP, _VP, _VP, _I, _I]), "bla_reshape_matrix_channels_f64": (_I, [_VP, _VP, _VP, _I, _I]),
+    "bla_conv_forward_f64": (_I, [_VP] * 7 + [_I] * 6), "bla_conv_backward_f64": (_I, [_VP] * 9 + [_I] * 6),
+    "bla_group_norm_f64": (_I, [_VP] * 5 + [_I] * 3), "bla_group_norm_ddx_f64": (_I, [_VP] * 6 + [_I] * 3),
+    "bla_relu_f64": (_I, [_VP, _VP, _SZ]), "bla_softmax_cols_f64": (_I, [_VP, _VP, _I, _I]), "bla_softmax_rows_f64": (_I, [_VP, _VP, _I, _I]),
     "bla_conv_out_hw": (_I, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "bla_im2col_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]), "bla_col2im_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
     "bla_kernels_to_matrix_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]), "bla_matrix_to_kernels_f32": (_I, [_VP, _VP, _VP, _I, _I, _I]),

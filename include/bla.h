@@ -215,6 +215,24 @@ BLA_API bla_status bla_col_sum_f64(void* stream, const double* d_m, int rows, in
 BLA_API bla_status bla_frobenius_f64(void* stream, const double* d_m, size_t n, double* d_out);              /* :150-158 */
 BLA_API bla_status bla_max_f64(void* stream, const double* d_m, size_t n, double* d_out);                    /* :160-168 */
 BLA_API bla_status bla_zscore_f64(void* stream, double* d_m, size_t n);                                      /* :170-185 (sigma through sqrtf, as there) */
+/* conv.h / norm.h / util.h in the same element type (csrc/bla_f64_conv.hip): the index maps of lib/conv.c, conv() / conv_ddx() with their two
+ * products on the f64 GEMM, group norm and its gradient, relu, the two softmaxes -- argument meaning as the _f32 entries of the same name. */
+BLA_API bla_status bla_im2col_f64(void* stream, const double* d_x, double* d_out, int h, int w, int k, int c_in, int stride);                 /* lib/conv.c:8-77 */
+BLA_API bla_status bla_col2im_f64(void* stream, const double* d_cols, double* d_out, int h, int w, int k, int c_n, int stride);              /* :80-135 */
+BLA_API bla_status bla_kernels_to_matrix_f64(void* stream, const double* d_kern, double* d_mat, int f_n, int c_n, int k);                     /* :138-153 */
+BLA_API bla_status bla_matrix_to_kernels_f64(void* stream, const double* d_mat, double* d_kern, int f_n, int c_n, int k);                     /* :156-171 */
+BLA_API bla_status bla_reshape_channels_matrix_f64(void* stream, double* d_channels, const double* d_matrix, int c_n, int hw);                /* :174-187, as written */
+BLA_API bla_status bla_reshape_matrix_channels_f64(void* stream, double* d_matrix, const double* d_channels, int c_n, int hw);                /* :190-203, as written */
+BLA_API bla_status bla_conv_forward_f64(void* stream, const double* d_x, const double* d_kern, double* d_im2col, double* d_kmat, double* d_product, double* d_output,
+                                        int h, int w, int k, int c_in, int f_n, int stride);                                                  /* :205-212 */
+BLA_API bla_status bla_conv_backward_f64(void* stream, const double* d_del_y, const double* d_im2col, const double* d_kmat, double* d_del_q, double* d_del_kmat,
+                                         double* d_del_kern, double* d_del_col, double* d_del_x, int h, int w, int k, int c_in, int f_n, int stride);   /* :214-229 */
+BLA_API bla_status bla_group_norm_f64(void* stream, const double* d_in, double* d_out, double* d_stdevs, double* d_means, int channels, int group_size, int hw);   /* lib/norm.c:5-50 */
+BLA_API bla_status bla_group_norm_ddx_f64(void* stream, const double* d_source, double* d_dest, const double* d_data, const double* d_means, const double* d_stdevs,
+                                          int channels, int group_size, int hw);                                                               /* :52-93 */
+BLA_API bla_status bla_relu_f64(void* stream, double* d, size_t n);                                                                            /* lib/util.c:7-13 */
+BLA_API bla_status bla_softmax_cols_f64(void* stream, double* d, int rows, int cols);                                                          /* :15-34 */
+BLA_API bla_status bla_softmax_rows_f64(void* stream, double* d, int rows, int cols);                                                          /* :36-55 */
 
 /* ---- convolution stages, lib/conv.c.  Images are contiguous [C][H][W]; kernels [F][C][k][k]; workspaces are
  * the reference's ConvData members (lib/conv.h:6-11): im2col [Ho*Wo][k*k*C], kernel_matrix [k*k*C][F],

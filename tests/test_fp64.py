@@ -125,3 +125,89 @@ def test_host_layer_in_double(dev):
     assert abs(H.frobenius_norm(mat(x)) - want) <= 1e-12 * want
     y = x.copy(); m = mat(y); H.matrix_scale(C.byref(m), -0.37); assert np.array_equal(y, x * -0.37)
     m = mat(y); H.matrix_transpose(C.byref(m)); assert (m.rows, m.cols) == (53, 37) and np.array_equal(y.reshape(53, 37), (x * -0.37).T)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference sources only exist in the build container")
+def test_reference_unet_program_links_with_double_typedef(tmp_path, pkg):
+    """model/cifar_unet.c, unchanged, against this repo's matrix.h / conv.h / norm.h / util.h / csv.h / cifar10.h / bmp.h under -DBLA_FP64."""
+    pkg.build_native()
+    tree = tmp_path / "tree"; (tree / "model").mkdir(parents=True); (tree / "lib").mkdir()
+    for f in os.listdir(LIB):
+        if f.endswith((".h", ".c")):
+            os.symlink(os.path.join(LIB, f), tree / "lib" / f)
+    os.symlink(os.path.join(REF, "model", "cifar_unet.c"), tree / "model" / "cifar_unet.c")
+    srcs = ["lib/" + f for f in ("matrix.c", "conv.c", "norm.c", "util.c", "csv.c", "cifar10.c", "bmp.c", "bla_host.c")]
+    r = subprocess.run(["gcc", "-std=gnu99", "-DBLA_FP64", "-Wno-unused-parameter", "-Wno-sign-compare", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+                        "-I", os.path.join(ROOT, "include"), "model/cifar_unet.c"] + srcs + ["-o", str(tmp_path / "prog"), "-L", CSRC, "-l:libbla_hip.so",
+                        f"-Wl,-rpath,{CSRC}", "-lm"], cwd=str(tree), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    syms = subprocess.run(["nm", "-D", str(tmp_path / "prog")], stdout=subprocess.PIPE, text=True).stdout
+    assert "bla_conv_forward_f64" in syms and "bla_group_norm_f64" in syms and "bla_conv_forward_f32" not in syms
+
+
+@pytest.mark.gpu
+def test_conv_norm_util_f64_against_the_oracle(dev, ora):
+    """conv.h / norm.h / util.h on the device in fp64 against the fp64 oracle (bit-identical to the reference compiled here) to 1e-12: conv() with all
+    four workspaces, conv_ddx() with all five outputs (stride 1; stride 2: the adjoint), group norm and its gradient, relu, both softmaxes."""
+    L = dev.lib(); chk = dev.native.check
+    E = lambda shape: dev.DeviceArray(shape, np.float64)
+    for i, (c, h, w, f, k, s) in enumerate([(3, 8, 8, 5, 3, 1), (6, 9, 7, 4, 3, 2), (4, 6, 6, 3, 1, 1), (5, 12, 10, 7, 5, 1)]):
+        x = uniform(1200 + i, (c, h, w), -1, 1); kern = uniform(1300 + i, (f, c, k, k), -0.5, 0.5)
+        fw = ora.conv_intended(x, kern, s)
+        ho, wo = ora.out_hw(h, w, s); hw, kkc = ho * wo, k * k * c
+        im, km, pr, out = E((hw, kkc)), E((kkc, f)), E((hw, f)), E((f, ho, wo))
+        dx_, dk_ = d64(dev, x), d64(dev, kern)          # (named: a temporary's memory would be handed to the next allocation)
+        chk(L.bla_conv_forward_f64(None, dx_.ptr, dk_.ptr, im.ptr, km.ptr, pr.ptr, out.ptr, h, w, k, c, f, s))
+        assert np.array_equal(im.numpy(), fw["im2col"]) and np.array_equal(km.numpy(), fw["kmat"])
+        assert close(pr.numpy(), fw["product"]) and close(out.numpy(), fw["output"])
+        dy = uniform(1400 + i, (f, ho, wo), -1, 1)
+        dq, dkm, dk, dcol, dx = E((hw, f)), E((kkc, f)), E((f, c, k, k)), E((hw, kkc)), E((c, h, w))
+        dy_ = d64(dev, dy)
+        chk(L.bla_conv_backward_f64(None, dy_.ptr, im.ptr, km.ptr, dq.ptr, dkm.ptr, dk.ptr, dcol.ptr, dx.ptr, h, w, k, c, f, s))
+        if s == 1:
+            bw = ora.conv_ddx_intended(dy, fw["im2col"], fw["kmat"], c, k)
+            for n, a in (("del_q", dq), ("del_kmat", dkm), ("del_kern", dk), ("del_col", dcol), ("del_x", dx)):
+                assert close(a.numpy(), bw[n]), (i, n)
+        else:
+            q = ora.reshape_matrix_channels(dy)
+            assert close(dk.numpy(), ora.matrix_to_kernels(fw["im2col"].T @ q, c, k)) and close(dx.numpy(), ora.col2im_adjoint(q @ fw["kmat"].T, c, h, w, k, s))
+    for i, (c, hh, gs) in enumerate([(8, 6, 4), (7, 5, 3), (32, 8, 32)]):
+        x = uniform(1500 + i, (c, hh, hh), -2, 2); g = uniform(1600 + i, (c, hh, hh), -1, 1)
+        want, sd, mu = ora.group_norm(x, gs)
+        ng = (c + gs - 1) // gs
+        o, dsd, dmu = E((c, hh, hh)), E((ng,)), E((ng,))
+        dx_, dg_, dmu_, dsd_ = d64(dev, x), d64(dev, g), d64(dev, mu), d64(dev, sd)
+        chk(L.bla_group_norm_f64(None, dx_.ptr, o.ptr, dsd.ptr, dmu.ptr, c, gs, hh * hh))
+        assert close(o.numpy(), want, 1e-11) and close(dsd.numpy(), sd) and close(dmu.numpy(), mu, 1e-11)
+        d = E((c, hh, hh))
+        chk(L.bla_group_norm_ddx_f64(None, dg_.ptr, d.ptr, dx_.ptr, dmu_.ptr, dsd_.ptr, c, gs, hh * hh))
+        assert close(d.numpy(), ora.group_norm_ddx(g, x, mu, sd, gs), 1e-10)
+    z = uniform(1700, (10, 37), -4, 4)
+    a = d64(dev, z); chk(L.bla_softmax_cols_f64(None, a.ptr, 10, 37)); assert close(a.numpy(), ora.softmax_cols(z.copy()))
+    a = d64(dev, z); chk(L.bla_softmax_rows_f64(None, a.ptr, 10, 37)); assert close(a.numpy(), ora.softmax_rows(z.copy()))
+    a = d64(dev, z); chk(L.bla_relu_f64(None, a.ptr, z.size)); assert np.array_equal(a.numpy(), np.maximum(z, 0))
+
+
+@pytest.mark.gpu
+def test_host_conv_in_double(dev, ora):
+    """lib/libbla_host_f64.so: conv() / group_norm() / softmax() of the drop-in headers with `double` data through their C signatures."""
+    H = C.CDLL(os.path.join(LIB, "libbla_host_f64.so"))
+
+    class ConvData(C.Structure):
+        _fields_ = [("im2col", PM), ("kernel_matrix", PM), ("product", PM), ("output", PM)]
+    c, h, w, f, k = 3, 8, 8, 4, 3
+    x = uniform(1800, (c, h, w), -1, 1); kern = uniform(1801, (f, c, k, k), -0.5, 0.5)
+    fw = ora.conv_intended(x, kern, 1)
+    X = (Matrix * c)(*[mat(x[i]) for i in range(c)])
+    rows = [(Matrix * c)(*[mat(kern[j, i]) for i in range(c)]) for j in range(f)]
+    K = (PM * f)(*[C.cast(r, PM) for r in rows])
+    im, km, pr = np.zeros((h * w, k * k * c)), np.zeros((k * k * c, f)), np.zeros((h * w, f)); out = np.zeros((f, h, w))
+    mim, mkm, mpr = mat(im), mat(km), mat(pr); O = (Matrix * f)(*[mat(out[j]) for j in range(f)])
+    data = ConvData(C.pointer(mim), C.pointer(mkm), C.pointer(mpr), C.cast(O, PM))
+    H.conv.argtypes = [PM, C.POINTER(PM), C.POINTER(ConvData), C.c_int, C.c_int, C.c_int]
+    H.conv(C.cast(X, PM), K, C.byref(data), c, f, 1)
+    assert np.array_equal(im, fw["im2col"]) and close(pr, fw["product"]) and close(out, fw["output"])
+    z = uniform(1802, (10, 16), -3, 3); want = ora.softmax_cols(z.copy())
+    H.softmax.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int]
+    H.softmax(z.ctypes.data_as(C.POINTER(C.c_double)), 10, 16)
+    assert close(z, want)
