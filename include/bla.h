@@ -168,7 +168,9 @@ BLA_API bla_status bla_gemm_group_f32(void* stream, const bla_gemm_desc* descs, 
  * (16-byte aligned operands, k a multiple of the slab depth); 6 wave-split-K 32x32 for latency-bound shapes (16: its 16x16-tile form, which the automatic
  * choice takes when the 32x32 tiling would leave CUs idle); 8/9 256x128-class
  * three-buffer tiles; 10 persistent 128x128; 11/12/13 the one-workgroup-per-CU half-slab kernels 256x256x16, 256x256x32, 128x512x16
- * and 14 their 128x128 form (whole tiles, plain alpha epilogue only).  A forced configuration that cannot take the call fails with
+ * and 14 / 15 / 17 their 128x128, 128x256 and 192x192 forms (whole tiles, plain alpha epilogue only; the automatic choice takes the one whose tile count
+ * is a whole number of rounds over the CUs); 18: 64x64 tiles on 32-deep slabs with two wave groups along K (1024^3-class products, one or two tiles
+ * per CU).  A forced configuration that cannot take the call fails with
  * BLA_ERR_INVALID; the automatic choice never does. */
 BLA_API bla_status bla_gemm_set_config(int config, int split_k);
 /* Name of the kernel variant the last bla_gemm_f32 call launched (for profiles/). */
