@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 #pragma unroll
 		for (int r = 0; r < 4; r++) m[r] = ok ? p.Z1[(size_t)(r0 + 4 * lq + r) * B + n0 + li] : 0.f;
 	};
-	if (p.backward) fetch_t(0, w2t[0], zm[0]);
+	if (p.backward == 1) fetch_t(0, w2t[0], zm[0]);
 	__syncthreads();
 	// ---- output layer (:231-234, 260-268): one 16 x 16 tile, K cut over the four waves, partial tiles folded in wave order ----
 	{
@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
 			dz2c[li][row] = v;
 		}
 	}
+	if (p.backward == 2) return;   // the short chain: dZ1 is a product of its own
 	__syncthreads();
 	// ---- dZ1 = (W2^T dZ2) (.) relu'(Z1) (:284-289): row tiles of 16 over n1, four per wave at n1 = 256 ----
 	auto tile_t = [&](int t, const float4 (&w)[C2], const float (&m)[4]) {
@@ -370,14 +371,18 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 
 /* Z1 = W1 (x / 255) + b1, A1 = relu; Z2, A2 likewise; Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) / n0; with the
  * loss / accuracy accumulators fed from the output layer's launch when enabled (model/mnist_nn.c:218-268). */
-static bool can_chain(const bla_mnist_nn* nn) {
+// 0: off; 1: the whole chain (layer 2, output layer, dZ2, dZ1); 2: the short chain (layer 2, output layer + softmax + loss gradient, dZ2 -- W2 is
+// streamed once, dZ1 stays a product beside dW3)
+static int can_chain(const bla_mnist_nn* nn) {
 	// OFF unless BLA_MNIST_CHAIN=1: measured SLOWER than the launches it replaces (chain 31 us + first layer 6.4 + grouped weight gradients 8.4 =
 	// 45.8 us per step against 32.0 us for six launches).  Every workgroup has to stream all of W2 twice (256 KB through ONE CU's memory path),
 	// and only batch / 16 = 16 CUs work; the five separate launches spread the same bytes over the whole chip.  Kept (and tested) as the
-	// record of that experiment; the three-product grouped launch it brought along is used by nothing else yet.
-	static const bool on = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return e && e[0] == '1'; }();
+	// record of that experiment; the three-product grouped launch it brought along is used by nothing else yet.  BLA_MNIST_CHAIN=2, the short chain
+	// (W2 streamed once, dZ1 left to a product: four launches per step), is no better: 43.6 us -- the chain launch itself takes ~27 us whatever it
+	// leaves out, i.e. it is the 16-workgroup forward part (128 KB of W2 into the registers of ONE CU per workgroup) that is slow, not dZ1.
+	static const int mode = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 0); }();
 	const int n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
-	return on && n1 % 16 == 0 && n1 <= kChainMaxN1 && n2 % 16 == 0 && n2 <= kChainMaxN2 && n3 <= 16 && B % 16 == 0 && nn->n[0] % 4 == 0;
+	return (n1 % 16 == 0 && n1 <= kChainMaxN1 && n2 % 16 == 0 && n2 <= kChainMaxN2 && n3 <= 16 && B % 16 == 0 && nn->n[0] % 4 == 0) ? mode : 0;
 }
 
 static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x_raw, const float* d_y, bool with_backward) {
@@ -390,7 +395,7 @@ static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x
 	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
 	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, d_x_raw, B, nn->a1, B, &ep); if (st) return st;         // :221-224
 	if (can_chain(nn)) {   // everything column-local that follows, forward and backward, in one launch
-		ChainArgs c = {nn->a1, nn->z1, W2, b2, W3, b3, d_y, nn->z2, nn->a2, nn->z3, nn->a3, nn->dz3, nn->dz2, nn->dz1, n1, n2, n3, B, with_backward ? 1 : 0,
+		ChainArgs c = {nn->a1, nn->z1, W2, b2, W3, b3, d_y, nn->z2, nn->a2, nn->z3, nn->a3, nn->dz3, nn->dz2, nn->dz1, n1, n2, n3, B, with_backward ? can_chain(nn) : 0,
 		               (float)(1 / (double)n0), nn->metrics_on ? nn->m_loss : nullptr, nn->metrics_on ? nn->m_correct : nullptr};
 		hipLaunchKernelGGL(mnist_chain_kernel, dim3(B / 16), dim3(256), 0, s, c);
 		BLA_HIP(hipGetLastError());
@@ -434,7 +439,8 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
 
 	st = forward_pass(nn, s, d_x_raw, d_y, true); if (st) return st;
-	if (can_chain(nn)) {
+	const int chain = can_chain(nn);
+	if (chain == 1) {
 		// dZ2 and dZ1 came out of the chain launch: what is left are the three weight gradients (+ bias gradients = row sums of dZ), one launch
 		bla_gemm_epilogue e3 = {}, e2 = {}, e1 = {};
 		e3.alpha = 1.f; e3.row_sum_a = fuse_db ? db3 : nullptr;
@@ -459,7 +465,7 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	// reference runs all five one after the other, :267-293), and putting the small dW2 beside the large dW1 hides it completely.
 	bla_gemm_epilogue em = {};
 	em.alpha = 1.f; em.relu_mask = nn->z2; em.ld_mask = B;
-	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st;          // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278
+	if (chain != 2) { st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st; }   // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278 (the short chain made it)
 	bla_gemm_epilogue eg = {};
 	eg.alpha = 1.f; eg.row_sum_a = fuse_db ? db3 : nullptr;
 	bla_gemm_epilogue em1 = {};
@@ -522,7 +528,8 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 	const float xs = 1 / 255.0F;
 	bla_status st = forward_pass(nn, s, x, y, true);
 	if (st) return st;
-	if (can_chain(nn)) {   // the three updates W_l += lr dZ_l A_{l-1}^T, b_l += lr rowsum(dZ_l) in one launch (the chain no longer reads W2 / W3)
+	const int chain = can_chain(nn);
+	if (chain == 1) {   // the three updates W_l += lr dZ_l A_{l-1}^T, b_l += lr rowsum(dZ_l) in one launch (the chain no longer reads W2 / W3)
 		bla_gemm_epilogue u3 = {}, u2 = {}, u1 = {};
 		u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
 		u2.alpha = lr; u2.beta = 1.f; u2.row_sum_a = b2; u2.row_sum_alpha = lr; u2.row_sum_beta = 1.f;
@@ -533,7 +540,7 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 	}
 	bla_gemm_epilogue em2 = {};
 	em2.alpha = 1.f; em2.relu_mask = nn->z2; em2.ld_mask = B;
-	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st;        // dZ2: last reader of W3
+	if (chain != 2) { st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st; }   // dZ2: last reader of W3 (or the short chain was)
 	bla_gemm_epilogue u3 = {}, em1 = {};
 	u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
 	em1.alpha = 1.f; em1.relu_mask = nn->z1; em1.ld_mask = B;
