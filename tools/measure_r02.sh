@@ -14,7 +14,7 @@ python tools/unet_bench.py > $out/unet_blocks.txt 2>&1
 python tools/unet_batch_bench.py 1 16 64 128 > $out/unet_batch.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/unet64_prof -- python3 tools/unet_batch_bench.py 64 > $out/unet64_prof.txt 2> $out/unet64_prof.err
 python tools/ew_bench.py 8192 > $out/ew_bench.txt 2>&1
-python tools/gemm_sweep.py --sizes 1024,2048,3072,4096,5120,6144,8192 --configs=-1 --layouts nn,nt,tn,tt --rounds 3 > $out/gemm_sweep.txt 2>&1
+python tools/gemm_sweep.py --sizes 1024,2048,3072,4096,5120,6144,8192 --configs=-1 --layouts nn,nt,tn,tt --rounds 3 --iters 40 > $out/gemm_sweep.txt 2>&1
 python tools/wsk_tile_compare.py > $out/wsk_tiles.txt 2>&1
 python tools/c_trainer_e2e.py 60000 3 256 > $out/c_trainer_e2e.txt 2>&1
 bash tools/profile_r02.sh $out/prof conv128 conv256 conv8 convs2 mnist mnist_dp softmax_cols transpose add colsum rowsum > $out/prof.log 2>&1
