@@ -161,6 +161,14 @@ bla_status bla_layer_net_backward_f32(bla_layer_net* m, void* stream, const floa
 		ep.alpha = 1.f; ep.beta = 1.f; ep.row_sum_a = m->params + m->b_off[l]; ep.row_sum_alpha = 1.f; ep.row_sum_beta = 1.f;
 		const float* a_prev = l > 1 ? m->nodes[l - 1] : m->input;
 		st = bla_gemm_f32(s, 0, 1, m->n[l], m->n[l - 1], B, m->delta, B, a_prev, B, W, m->n[l - 1], &ep);
+		if (st == BLA_ERR_INVALID) {   // a product too large for the latency-bound kernel (the accumulated row sum lives there): the bias step as its own pass
+			ep.row_sum_a = nullptr;
+			st = bla_gemm_f32(s, 0, 1, m->n[l], m->n[l - 1], B, m->delta, B, a_prev, B, W, m->n[l - 1], &ep);
+			if (st) return st;
+			st = bla_col_sum_f32(s, m->delta, m->n[l], B, m->h, BLA_COLSUM_INTENDED);   // (h of this layer has been consumed above)
+			if (st) return st;
+			st = bla_add_f32(s, m->params + m->b_off[l], m->h, (size_t)m->n[l]);
+		}
 		if (st) return st;
 		g = gn; gn = gn == m->g ? m->g2 : m->g;
 	}

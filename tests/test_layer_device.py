@@ -87,3 +87,28 @@ def test_batch_sums_the_single_column_steps(pkg, ora):
         assert np.linalg.norm((got_w - ws[i]) - dw[i]) <= 1e-5 * np.linalg.norm(dw[i]), i
         assert np.linalg.norm((got_b - bs[i]) - db[i]) <= 1e-5 * np.linalg.norm(db[i]), i
     chk(L.bla_layer_net_destroy(h))
+
+
+def test_wide_layers_take_the_separate_bias_pass(pkg):
+    """Layers too large for the latency-bound GEMM (its epilogue carries the accumulated bias step): 512 -> 2048 -> 16 at B = 64 against numpy."""
+    pkg.init(0)
+    L = pkg.lib(); chk = pkg.native.check
+    sizes, B, lr = [512, 2048, 16], 64, 0.01
+    ws = [uniform(9800 + i, (sizes[i + 1], sizes[i]), -0.05, 0.05, F32) for i in range(2)]
+    bs = [uniform(9810 + i, (sizes[i + 1], 1), -0.1, 0.1, F32) for i in range(2)]
+    x = uniform(9820, (sizes[0], B), -1, 1, F32); e = uniform(9821, (sizes[-1], B), 0, 1, F32)
+    h = make(pkg, sizes, B, 2, 0.0)        # ReLU
+    for i in range(2):
+        put(pkg, L.bla_layer_net_weights(h, i + 1), ws[i]); put(pkg, L.bla_layer_net_biases(h, i + 1), bs[i])
+    dx, de = pkg.to_device(x), pkg.to_device(e)
+    chk(L.bla_layer_net_forward_f32(h, None, dx.ptr)); chk(L.bla_layer_net_backward_f32(h, None, de.ptr, lr))
+    w = [a.astype(np.float64) for a in ws]; b = [a.astype(np.float64) for a in bs]
+    z1 = w[0] @ x + b[0]; a1 = np.maximum(z1, 0); z2 = w[1] @ a1 + b[1]; a2 = np.maximum(z2, 0)
+    h2 = (z2 > 0) * 2 * (a2 - e); d2 = -lr * h2
+    h1 = (z1 > 0) * (w[1].T @ h2); d1 = -lr * h1
+    want = [(w[0] + d1 @ x.T, b[0] + d1.sum(1, keepdims=True)), (w[1] + d2 @ a1.T, b[1] + d2.sum(1, keepdims=True))]
+    for i in range(2):
+        gw = get(pkg, L.bla_layer_net_weights(h, i + 1), ws[i].shape); gb = get(pkg, L.bla_layer_net_biases(h, i + 1), bs[i].shape)
+        assert np.linalg.norm((gw - ws[i]) - (want[i][0] - w[i])) <= 1e-4 * np.linalg.norm(want[i][0] - w[i]), i
+        assert np.linalg.norm((gb - bs[i]) - (want[i][1] - b[i])) <= 1e-4 * np.linalg.norm(want[i][1] - b[i]), i
+    chk(L.bla_layer_net_destroy(h))
