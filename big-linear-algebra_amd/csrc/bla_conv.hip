@@ -1095,7 +1095,9 @@ static bool parity_dgrad_applies(int batch, int h, int w, int k, int c_in, int f
 		if (P.n == 0 || Q.n == 0) return false;
 	}
 	const ParityTaps a = parity_taps(k, gm.pt, 0), b = parity_taps(k, gm.pt, 1), c = parity_taps(k, gm.pl, 0), d = parity_taps(k, gm.pl, 1);
-	return a.n + b.n == k && c.n + d.n == k && gm.ho == h / 2 && gm.wo == w / 2;
+	// (32-bit gather offsets: the padded copy of del_y and a class plane must stay under 2 GiB, or the dilated form takes the call)
+	const size_t copy_floats = (size_t)batch * f_n * (gm.ho + 2) * ((gm.wo + 2 + 3) / 4 * 4), cls_floats = (size_t)batch * c_in * (h / 2) * (w / 2);
+	return a.n + b.n == k && c.n + d.n == k && gm.ho == h / 2 && gm.wo == w / 2 && copy_floats < ((size_t)1 << 29) && cls_floats < ((size_t)1 << 29);
 }
 
 static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, const float* d_kern, float* d_del_x, float* d_scratch, int batch, int h, int w, int k,
