@@ -323,12 +323,26 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": best["device_ms_per_step"],
                        "algorithmic_flops_per_launch": per_gpu_batch * FLOP_PER_SAMPLE,
                        "note": "whole step (6-7 dependent launches), per GPU; latency-bound, see profiles/r02_mnist_*"}
+    if world == 1 and per_gpu_batch == 256:
+        sec["roofline"]["traffic"], src = committed_traffic("mnist")
+        if src:
+            sec["roofline"]["traffic_source"] = src
     if world > 1:
         sec["exchange_fallback"] = chosen != "direct" and os.environ.get("BLA_BENCH_EXCHANGE", "both") != "rccl"
         sec["exchange_fault"] = fault
         sec["legs"] = legs
     sec.update(detail)
     return sec, fault
+
+
+def committed_traffic(target):
+    """HBM-side traffic per iteration of a secondary / tertiary workload from the committed rocprofv3 --pmc summary of the same workload
+    (profiles/r02/<target>.summary.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; it cannot be collected from inside this process)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02", target + ".summary.json")))
+        return int(d["iteration"]["traffic_bytes"]), f"profiles/r02/{target}.summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def run_conv(bla, stream, barrier, steps=20, warmup=5):
@@ -375,6 +389,9 @@ def run_conv(bla, stream, barrier, steps=20, warmup=5):
                         "frac": round(tf_all / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": round(f_ms + b_ms, 4),
                         "algorithmic_flops_per_launch": 3 * fl, "forward_ms": round(f_ms, 4), "forward_frac": round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
                         "backward_ms": round(b_ms, 4), "backward_frac": round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4)}}
+    res["roofline"]["traffic"], src = committed_traffic("conv128")
+    if src:
+        res["roofline"]["traffic_source"] = src
     return res, (x, kern, dy, out, dk, dx)
 
 
