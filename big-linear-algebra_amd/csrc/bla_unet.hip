@@ -421,10 +421,10 @@ bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* 
 bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
                                            const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
                                            int w, int cin, int cout, int k, int tdim, int group_size) {
-	if (batch == 1) return bla_resnet_backward_f32(stream, d_del_out, d_x, d_temb, p, ws, g, sc, d_del_x, h, w, cin, cout, k, tdim, group_size);
+	if (batch == 1 && d_del_x) return bla_resnet_backward_f32(stream, d_del_out, d_x, d_temb, p, ws, g, sc, d_del_x, h, w, cin, cout, k, tdim, group_size);
 	BLA_ENTER();
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
-	BLA_REQUIRE(d_del_out && d_x && d_temb && p && ws && g && sc && d_dtb && d_del_x && g->conv1 && g->conv2 && g->time_w && g->time_b && sc->g_out_a &&
+	BLA_REQUIRE(d_del_out && d_x && d_temb && p && ws && g && sc && d_dtb && g->conv1 && g->conv2 && g->time_w && g->time_b && sc->g_out_a &&
 	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
 	const int hw = h * w;
@@ -434,11 +434,14 @@ bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float*
 	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
 	st = batch_sum(stream, d_dtb, g->time_b, batch, (size_t)cout); if (st) return st;
 	st = bla_gemm_f32(stream, 1, 0, tdim, cout, batch, d_temb, tdim, d_dtb, cout, g->time_w, cout, nullptr); if (st) return st;
-	st = bla_conv2d_backward_batched_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, sc->g_in, sc->flip, batch, h, w, k, cin, cout, 1); if (st) return st;   // :1202-1205
-	st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st;
+	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
+	// gradients and the last norm gradient are not formed, the weight gradients are
+	st = bla_conv2d_backward_batched_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1);   // :1202-1205
+	if (st) return st;
+	if (d_del_x) { st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st; }
 	if (cin != cout) {                                                                                                                  // :1208-1220
-		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, sc->g_in, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
-		return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)batch * cin * hw);
+		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
+		if (d_del_x) return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)batch * cin * hw);
 	}
 	return BLA_OK;
 }

@@ -440,7 +440,8 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 	// first, :1430-1435
 	TRY(conv(m->down[0], b, m->res[1].result, a));
 	TRY(bla_add_f32(stream, a, m->gskip[3], n0 * B));
-	TRY(res(1, a, m->res[0].result, b)); TRY(res(0, b, m->last_x, a));
+	TRY(res(1, a, m->res[0].result, b));
+	TRY(res(0, b, m->last_x, nullptr));   // nothing consumes the gradient of the image: the first block forms its weight gradients only
 	return BLA_OK;
 }
 #undef TRY

@@ -334,7 +334,8 @@ BLA_API bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out,
  * images): x / out / del_* [B][C][H*W], temb [B][T] (every image its own time step), d_drop [B][Cout*H*W]; every workspace / scratch buffer is B
  * times its single-image size (tdense [B][Cout], mu / sd [B][groups]).  The convolutions run as batched implicit GEMMs, the norms over B*C
  * channels, each per-image product of the attention block as one launch over the batch.  batch = 1 is the single-image entry point.
- * d_partials: [B][C*d] scratch (per-image weight gradients before their sum); d_dtb: [B][Cout] scratch. */
+ * d_partials: [B][C*d] scratch (per-image weight gradients before their sum); d_dtb: [B][Cout] scratch.  bla_resnet_backward_batched_f32 takes
+ * d_del_x = NULL when nothing consumes the gradient of the block's input (a network's first block): only the weight gradients are formed. */
 BLA_API bla_status bla_gemm_batched_f32(void* stream, int transa, int transb, int m, int n, int k, const float* A, int lda, long stride_a, const float* B, int ldb,
                                         long stride_b, float* C, int ldc, long stride_c, int batch, const bla_gemm_epilogue* ep, long stride_pre);
 BLA_API bla_status bla_group_norm_relu_batched_f32(void* stream, int batch, const float* d_in, float* d_out, float* d_stdevs, float* d_means, int channels,

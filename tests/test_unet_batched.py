@@ -55,7 +55,7 @@ def resnet_case(pkg, batch, cin, cout, hh, tdim, gs, seed):
     D = {n: pkg.to_device(v) for n, v in I.items() if v is not None}
     params = N.ResnetParams(D["k1"].ptr, D["k2"].ptr, D["tw"].ptr, D["tb"].ptr, D["kres"].ptr if cin != cout else None)
 
-    def run(b, x, temb, dr, del_out, keep=D):     # (keep: the parameter buffers live as long as this function does -- `params` holds bare addresses)
+    def run(b, x, temb, dr, del_out, keep=D, want_del_x=True):     # (keep: the parameter buffers live as long as this function does -- `params` holds bare addresses)
         """one forward + backward over b images -> (saved tensors, gradients)"""
         W = dict(mu1=pkg.empty((b, g1)), sd1=pkg.empty((b, g1)), relu1=pkg.empty((b, cin, hh, hh)), c1=pkg.empty((b, cout, hh, hh)), tdense=pkg.empty((b, cout)),
                  mu2=pkg.empty((b, g2)), sd2=pkg.empty((b, g2)), relu2=pkg.empty((b, cout, hh, hh)), dp=pkg.empty((b, cout, hh, hh)), c2=pkg.empty((b, cout, hh, hh)),
@@ -70,8 +70,8 @@ def resnet_case(pkg, batch, cin, cout, hh, tdim, gs, seed):
         S = dict(a=pkg.empty((b, cout, hh, hh)), b=pkg.empty((b, cout, hh, hh)), c=pkg.empty((b, cin, hh, hh)), f=pkg.empty((cout * max(cin, cout) * 9,)))
         scratch = N.ResnetScratch(S["a"].ptr, S["b"].ptr, S["c"].ptr, S["f"].ptr)
         dtb = pkg.empty((b, cout)); del_x = pkg.empty((b, cin, hh, hh)).fill_bytes(0xFF)
-        chk(L.bla_resnet_backward_batched_f32(None, b, dg.ptr, dx.ptr, dt.ptr, C.byref(params), C.byref(ws), C.byref(grads), C.byref(scratch), dtb.ptr, del_x.ptr,
-                                              hh, hh, cin, cout, 3, tdim, gs))
+        chk(L.bla_resnet_backward_batched_f32(None, b, dg.ptr, dx.ptr, dt.ptr, C.byref(params), C.byref(ws), C.byref(grads), C.byref(scratch), dtb.ptr,
+                                              del_x.ptr if want_del_x else None, hh, hh, cin, cout, 3, tdim, gs))
         fw = {n: W[n].numpy() for n in ("relu1", "c1", "tdense", "relu2", "dp", "c2")}; fw["result"] = result.numpy(); fw["del_x"] = del_x.numpy()
         gr = {n: G[n].numpy() for n in (["k1", "k2", "tw", "tb"] + (["kres"] if cin != cout else []))}
         return fw, gr
@@ -111,6 +111,18 @@ def test_batched_resnet_block(pkg, cfg):
         for n in gr:
             want = ga[n].astype(np.float64) + gb[n]
             assert np.linalg.norm(gr[n] - want) <= tol * np.linalg.norm(want) + 1e-12, (cfg, n, flips)
+
+
+@pytest.mark.parametrize("cfg", [(5, 3, 32, 8, 16, 32), (1, 3, 32, 8, 16, 32), (4, 48, 48, 12, 24, 16)])
+def test_resnet_backward_without_the_input_gradient(pkg, cfg):
+    """d_del_x = NULL (a network's first block): the weight, time and residual-kernel gradients are what they are with it."""
+    pkg.init(0)
+    batch, cin, cout, hh, tdim, gs = cfg
+    I, drop, run = resnet_case(pkg, batch, cin, cout, hh, tdim, gs, 8300 + 10 * cin)
+    _, full = run(batch, I["x"], I["temb"], drop, I["del_out"])
+    _, only = run(batch, I["x"], I["temb"], drop, I["del_out"], want_del_x=False)
+    for n in full:
+        assert np.linalg.norm(only[n] - full[n]) <= 1e-5 * np.linalg.norm(full[n]) + 1e-12, (cfg, n)
 
 
 @pytest.mark.parametrize("cfg", [(5, 32, 8, 16), (3, 24, 4, 8), (16, 256, 16, 16)])
