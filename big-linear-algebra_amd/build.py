@@ -73,10 +73,9 @@ def build_hip(force=False, verbose=False):
         if tl:  # one HIP runtime per process: bind to the runtime torch will load (see module docstring)
             link = ["g++", "-shared", "-fPIC", "-o", HIP_SO] + objs + ["-L", tl, "-l:libamdhip64.so", f"-Wl,-rpath,{tl}",
                     "-Wl,--no-undefined"]
-            # bla_rccl.hip: the same RCCL torch.distributed's "nccl" backend uses (one collective library per process)
-            link += ["-l:librccl.so"] if os.path.exists(os.path.join(tl, "librccl.so")) else ["-L", "/opt/rocm/lib", "-lrccl"]
+            link += ["-ldl"]   # bla_rccl.hip opens librccl.so.1 on first use (no link dependency: a box without RCCL still loads this library)
         else:
-            link += ["-L", "/opt/rocm/lib", "-lrccl"]
+            link += ["-ldl"]
         _run(link)
     return HIP_SO
 

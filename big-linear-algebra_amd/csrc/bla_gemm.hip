@@ -289,8 +289,10 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false,
           int WK = 1>
 __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
-	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && BN == 128 && BK == 16 && WM * WN == 4),
-	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image, mode 4 gathers A and takes a K-contiguous B");
+	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && (BN == 128 || (BN == 256 && GATHER == 3 && HS)) && BK == 16 && WM * WN == 4),
+	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image (mode 3 on the half-slab pipeline: [16][256] too), mode 4 gathers A and takes a K-contiguous B");
+	// mode 3: one wave-instruction of the B image (1 KiB = 256 floats) covers G3_RPI k-rows of BN / 4 sixteen-byte chunks each
+	constexpr int G3_CPR = BN / 4, G3_RPI = 64 / (G3_CPR < 64 ? G3_CPR : 64);
 	constexpr int NW = WM * WN * WK;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8, KKW = KK / WK;   // KKW: k-parts of a slab this wave multiplies
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	}
 	int g3_base = 0;              // mode 3: padded-image offset of this lane's four columns
 	if (GATHER == 3) {
-		int n = min(n0 + (lane & 31) * 4, p.N - 4);
+		int n = min(n0 + (lane % G3_CPR) * 4, p.N - 4);
 		int b = n / p.g_HWo, r = n - b * p.g_HWo;
 		g3_base = p.g_ntab[r].x + b * p.g_img_stride;
 	}
@@ -609,8 +611,8 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		if (GATHER == 3) {
 #pragma unroll
 			for (int i = 0; i < B_NI; i++) {
-				const int row = __builtin_amdgcn_readfirstlane(g_k + (wave * B_NI + i) * 2);
-				hs_tap[i][0] = p.g_ktab[row].x; hs_tap[i][1] = p.g_ktab[row + 1].x;
+				const int row = __builtin_amdgcn_readfirstlane(g_k + (wave * B_NI + i) * G3_RPI);
+				hs_tap[i][0] = p.g_ktab[row].x; hs_tap[i][1] = G3_RPI == 2 ? p.g_ktab[row + 1].x : 0;
 			}
 		}
 		if (GATHER == 4) {
@@ -634,8 +636,8 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		} else {
 			const int i = d - A_NI;
 			if (GATHER == 3) {   // gathered operand: four consecutive output pixels = four consecutive floats of the padded copy, tap from the scalar table
-				const int idx = wave * B_NI + i;   // the instruction covers k-rows 2 idx (lanes 0-31) and 2 idx + 1: their tap offsets were loaded a slab ahead (hs_tap)
-				const float* src = p.g_img + (g3_base + ((lane >> 5) ? hs_tap[i][1] : hs_tap[i][0]));
+				const int idx = wave * B_NI + i;   // the instruction covers k-rows 2 idx (lanes 0-31) and 2 idx + 1 (BN = 256: the one row idx): their tap offsets were loaded a slab ahead (hs_tap)
+				const float* src = p.g_img + (g3_base + ((G3_RPI == 2 && (lane >> 5)) ? hs_tap[i][1] : hs_tap[i][0]));
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + idx * 256), 16, 0, 0);
 			} else if (B_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, voff_b[i], soff_b, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb[i] + g_adv_b), (lds_ptr_t)(base + A_SZ + (wave * B_NI + i) * 256), 16, 0, 0);
@@ -1645,6 +1647,12 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
 	a.g_img = img; a.g_zero = zero_word(); a.g_ktab = ktab; a.g_ntab = ntab; a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
 	a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
+	// mode 3 on the half-slab pipeline: 128 x 256 tiles (waves 2 x 2, each 64 x 128: half the LDS reads and DMA instructions per MFMA of the 128 x 128 tile)
+	// once they give every CU a workgroup; BLA_CONV_BN=128 keeps the 128 x 128 tile
+	static const int force_bn = [] { const char* e = getenv("BLA_CONV_BN"); return e ? atoi(e) : 0; }();
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	const bool bn256 = mode == 3 && gather_hs(mode, M, N) && N % 256 == 0 && force_bn != 128 && ((long)(M / 128) * (N / 256) >= cus || force_bn == 256) && gather3_splits(M, N, K) == 1;
+	if (bn256) a.tiles_n = N / 256;
 	const int splits = mode == 3 ? gather3_splits(M, N, K) : gather_gemm_splits(mode, batch, M, N, HWo);
 	a.k_per_split = (mode == 2 || mode == 4) ? gather_k_per_split(mode, batch, M, N, HWo) : mode == 3 ? (K / 16 + splits - 1) / splits * 16 : K;
 	a.splits = splits; a.slab = nullptr;
@@ -1662,7 +1670,8 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 		BLA_REQUIRE(mode == 3 && hs && splits == 1, BLA_ERR_INVALID, "the fused convolution epilogue needs the half-slab forward kernel in one pass over K (gather3_fuses_epilogue)");
 		a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2;
 	}
-	if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
+	if (bn256) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, 2 * (128 + 256) * 16 * sizeof(float), s, a);
+	else if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
 	else if (hs) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true>), grid, block, lds_bytes, s, a);
 	else if (mode == 1) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 1>), grid, block, lds_bytes, s, a);
 	else if (mode == 2) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 2>), grid, block, lds_bytes, s, a);

@@ -11,6 +11,7 @@ namespace bla {
 
 struct Context {
 	bool ready = false;
+	int users = 0;                  // threads on which this context is current (bla_context_set_current); guarded by the runtime's mutex
 	int device = -1;
 	hipStream_t stream = nullptr;
 	void* workspace = nullptr;      // grow-only scratch (split-K slabs, reductions)
@@ -71,11 +72,15 @@ void dp_advance(bla_dp* dp);
 // between library calls (MNIST sampler, U-Net dropout).  HIP runtime initialisation and RCCL communicator set-up draw from / reseed rand()
 // themselves (measured: tests/c/rand_stream.c), which would shift the program's stream against the reference's CPU run.  glibc's rand() is
 // random() on the current state array: park the caller's state while those calls run and put it back afterwards.
+// Process-wide and nestable: one host thread per rank may be inside the library at once (bla.h), and a blocking call such as
+// ncclCommInitRank must not hold a lock the other ranks' threads need.  The FIRST guard to be entered parks the caller's state (initstate
+// onto a scratch array in static storage), the LAST one to leave puts it back; only the depth counter and the swap are under a mutex, never
+// the guarded call.  While any guard is open, rand() draws (the runtime's, RCCL's) go to the scratch state.
+void rand_guard_enter();
+void rand_guard_leave();
 struct RandStreamGuard {
-	char scratch[128];
-	char* saved;
-	RandStreamGuard() { saved = initstate(1u, scratch, sizeof scratch); }
-	~RandStreamGuard() { (void)setstate(saved); }
+	RandStreamGuard() { rand_guard_enter(); }
+	~RandStreamGuard() { rand_guard_leave(); }
 	RandStreamGuard(const RandStreamGuard&) = delete;
 	RandStreamGuard& operator=(const RandStreamGuard&) = delete;
 };

@@ -35,6 +35,20 @@ bla_status require_ready() {
 	return BLA_OK;
 }
 
+// libc rand() state of the caller, parked while HIP / RCCL calls that draw from rand() run (bla_internal.h)
+static std::mutex g_rand_mu;
+static int g_rand_depth = 0;
+static char g_rand_scratch[128];
+static char* g_rand_saved = nullptr;
+void rand_guard_enter() {
+	std::lock_guard<std::mutex> lk(g_rand_mu);
+	if (g_rand_depth++ == 0) g_rand_saved = initstate(1u, g_rand_scratch, sizeof g_rand_scratch);
+}
+void rand_guard_leave() {
+	std::lock_guard<std::mutex> lk(g_rand_mu);
+	if (--g_rand_depth == 0 && g_rand_saved) { (void)setstate(g_rand_saved); g_rand_saved = nullptr; }
+}
+
 bla_status ensure_workspace(size_t bytes, void** out) {
 	Context& c = ctx();
 	if (bytes > c.workspace_bytes) {
@@ -121,7 +135,20 @@ int bla_device_count(void) {
 	return n;
 }
 
-// create stream / counters of one context on `device` (the caller holds g_mu)
+// release whatever a context holds, ready or not (a context whose set-up failed half way holds a stream but is not ready)
+static void close_context(Context& c) {
+	if (!c.stream && !c.workspace && !c.workspace2 && !c.tile_counters) { c = Context(); return; }
+	RandStreamGuard keep_callers_rand_stream;
+	if (c.device >= 0) { (void)hipSetDevice(c.device); (void)hipDeviceSynchronize(); }
+	if (c.stream) (void)hipStreamDestroy(c.stream);
+	if (c.workspace) (void)hipFree(c.workspace);
+	if (c.workspace2) (void)hipFree(c.workspace2);
+	if (c.tile_counters) (void)hipFree(c.tile_counters);
+	c = Context();
+}
+
+// create stream / counters of one context on `device` (the caller holds g_mu).  On failure nothing stays allocated and the calling thread is
+// back on the device it was on.
 static bla_status open_context(Context& c, int device) {
 	RandStreamGuard keep_callers_rand_stream;   // the first HIP calls of a process initialise the runtime, which draws from rand()
 	int n = bla_device_count();
@@ -130,35 +157,33 @@ static bla_status open_context(Context& c, int device) {
 		return BLA_ERR_NO_DEVICE;
 	}
 	BLA_REQUIRE(device >= 0 && device < n, BLA_ERR_INVALID, "device %d out of range [0,%d)", device, n);
-	BLA_HIP(hipSetDevice(device));
-	hipDeviceProp_t prop;
-	BLA_HIP(hipGetDeviceProperties(&prop, device));
-	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-		set_error("device %d is %s; libbla_hip.so carries gfx950 code objects only", device, prop.gcnArchName);
-		return BLA_ERR_NO_DEVICE;
+	int before = -1;
+	(void)hipGetDevice(&before);
+	auto body = [&]() -> bla_status {
+		BLA_HIP(hipSetDevice(device));
+		c.device = device;
+		hipDeviceProp_t prop;
+		BLA_HIP(hipGetDeviceProperties(&prop, device));
+		if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+			set_error("device %d is %s; libbla_hip.so carries gfx950 code objects only", device, prop.gcnArchName);
+			return BLA_ERR_NO_DEVICE;
+		}
+		BLA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+		BLA_HIP(hipMalloc((void**)&c.tile_counters, (16384 + 64) * sizeof(unsigned)));   // + 64 words that stay zero (zero_word())
+		// zeroed on the context's own stream and waited for: the stream is non-blocking, a NULL-stream memset would not order against it
+		BLA_HIP(hipMemsetAsync(c.tile_counters, 0, (16384 + 64) * sizeof(unsigned), c.stream));
+		BLA_HIP(hipStreamSynchronize(c.stream));
+		c.num_cus = prop.multiProcessorCount;
+		strncpy(c.arch, prop.gcnArchName, sizeof(c.arch) - 1);
+		c.ready = true;
+		return BLA_OK;
+	};
+	bla_status st = body();
+	if (st) {
+		close_context(c);
+		if (before >= 0) (void)hipSetDevice(before);
 	}
-	BLA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-	BLA_HIP(hipMalloc((void**)&c.tile_counters, (16384 + 64) * sizeof(unsigned)));   // + 64 words that stay zero (zero_word())
-	// zeroed on the context's own stream and waited for: the stream is non-blocking, a NULL-stream memset would not order against it
-	BLA_HIP(hipMemsetAsync(c.tile_counters, 0, (16384 + 64) * sizeof(unsigned), c.stream));
-	BLA_HIP(hipStreamSynchronize(c.stream));
-	c.device = device;
-	c.num_cus = prop.multiProcessorCount;
-	strncpy(c.arch, prop.gcnArchName, sizeof(c.arch) - 1);
-	c.ready = true;
-	return BLA_OK;
-}
-
-static void close_context(Context& c) {
-	if (!c.ready) return;
-	RandStreamGuard keep_callers_rand_stream;
-	(void)hipSetDevice(c.device);
-	(void)hipDeviceSynchronize();
-	(void)hipStreamDestroy(c.stream);
-	if (c.workspace) (void)hipFree(c.workspace);
-	if (c.workspace2) (void)hipFree(c.workspace2);
-	if (c.tile_counters) (void)hipFree(c.tile_counters);
-	c = Context();
+	return st;
 }
 
 bla_status bla_init(int device) {
@@ -168,9 +193,7 @@ bla_status bla_init(int device) {
 		return BLA_OK;
 	}
 	close_context(g_ctx);   // switching device: drop the old stream / workspace
-	bla_status st = open_context(g_ctx, device);
-	if (st) close_context(g_ctx);
-	return st;
+	return open_context(g_ctx, device);
 }
 
 bla_status bla_shutdown(void) {
@@ -189,7 +212,7 @@ bla_status bla_context_create(bla_context** out, int device) {
 	std::lock_guard<std::mutex> lk(g_mu);
 	bla_context* c = new bla_context();
 	bla_status st = open_context(c->c, device);
-	if (st) { close_context(c->c); delete c; }
+	if (st) delete c;
 	else *out = c;
 	Context& cur = ctx();   // open_context moved this thread to `device`: go back to where the caller was
 	if (cur.ready) (void)hipSetDevice(cur.device);
@@ -197,22 +220,35 @@ bla_status bla_context_create(bla_context** out, int device) {
 }
 
 bla_status bla_context_set_current(bla_context* c) {
-	t_ctx = c ? &c->c : nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		if (t_ctx) t_ctx->users--;
+		t_ctx = c ? &c->c : nullptr;
+		if (t_ctx) t_ctx->users++;
+	}
 	Context& cur = ctx();
 	if (cur.ready) BLA_HIP(hipSetDevice(cur.device));
 	return BLA_OK;
 }
 
+/* Refused (BLA_ERR_INVALID) while the context is current on ANOTHER thread: that thread's next bla_* call would use freed memory. */
 bla_status bla_context_destroy(bla_context* c) {
 	if (!c) return BLA_OK;
 	std::lock_guard<std::mutex> lk(g_mu);
-	if (t_ctx == &c->c) t_ctx = nullptr;
+	const int mine = t_ctx == &c->c ? 1 : 0;
+	BLA_REQUIRE(c->c.users - mine == 0, BLA_ERR_INVALID, "the context is still current on %d other thread(s): bla_context_set_current(NULL) there first", c->c.users - mine);
+	if (mine) { t_ctx = nullptr; c->c.users--; }
 	close_context(c->c);
 	delete c;
 	Context& cur = ctx();
 	if (cur.ready) (void)hipSetDevice(cur.device);
 	return BLA_OK;
 }
+
+/* The calling program's libc rand() stream around HIP / RCCL calls it makes ITSELF between library calls (the library's own entry points do
+ * this internally): enter parks the stream, leave puts it back; nestable, process-wide, any thread. */
+void bla_rand_guard_enter(void) { rand_guard_enter(); }
+void bla_rand_guard_leave(void) { rand_guard_leave(); }
 
 int bla_is_initialized(void) { return ctx().ready ? 1 : 0; }
 const char* bla_last_error(void) { return g_err; }

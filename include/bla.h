@@ -63,7 +63,15 @@ BLA_API bla_status bla_device_name(char* buf, int buflen);   /* gcnArchName of t
 typedef struct bla_context bla_context;
 BLA_API bla_status bla_context_create(bla_context** out, int device);
 BLA_API bla_status bla_context_set_current(bla_context* c);
-BLA_API bla_status bla_context_destroy(bla_context* c);
+BLA_API bla_status bla_context_destroy(bla_context* c);   /* BLA_ERR_INVALID while the context is current on another thread (set NULL there first, also before that thread ends) */
+
+/* libc rand() belongs to the calling program (the reference's programs seed it once and draw from it between library calls: sampler
+ * lib/mnist_csv2.c:36-62, dropout model/cifar_unet.c:1032-1042), but HIP runtime start-up and RCCL set-up draw from it too.  Every library
+ * entry that reaches them parks the caller's stream by itself; a host program that makes such calls ITSELF brackets them with this pair.
+ * Process-wide and nestable: the first enter (any thread) parks the stream, the last leave puts it back.  While a guard is open other threads
+ * must not draw from rand() and expect the program's stream. */
+BLA_API void bla_rand_guard_enter(void);
+BLA_API void bla_rand_guard_leave(void);
 
 BLA_API bla_status bla_malloc(void** d_ptr, size_t bytes);
 BLA_API bla_status bla_free(void* d_ptr);
@@ -480,12 +488,21 @@ BLA_API bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stre
 BLA_API bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
 
 /* ---- the same exchange through the library collective: RCCL ncclAllReduce(ncclFloat, ncclSum) over xGMI (north_star) ----
- * Rank 0 makes the 128-byte unique id, the host program hands it to the other ranks over any channel, every rank creates its
- * communicator on its current context's device (one process per GPU, or one context per GPU in one process). */
+ * librccl is opened on first use, not linked: bla_dp_rccl_available() says whether it could be (a single-GPU box needs none).
+ * One process (or one host thread) per rank: rank 0 makes the 128-byte unique id, the host program hands it to the other ranks over any
+ * channel, every rank calls bla_dp_rccl_init on its current context's device -- ncclCommInitRank is COLLECTIVE and BLOCKS until all ranks
+ * have called it, so a single host thread must not call it rank after rank.
+ * ONE host thread driving all ranks of a process: bla_dp_rccl_init_all (ncclCommInitAll, distinct devices), then per step every rank's
+ * bla_dp_rccl_allreduce_f32 between bla_dp_rccl_group_begin / _end.
+ * Not executed with world > 1 anywhere yet: the build pool has one-GPU boxes and RCCL refuses duplicate devices (tests: world 1). */
 typedef struct bla_rccl bla_rccl;
 #define BLA_RCCL_ID_BYTES 128
+BLA_API int bla_dp_rccl_available(void);
 BLA_API bla_status bla_dp_rccl_unique_id(void* id128);
-BLA_API bla_status bla_dp_rccl_init(bla_rccl** out, const void* id128, int rank, int world);   /* ncclCommInitRank; collective */
+BLA_API bla_status bla_dp_rccl_init(bla_rccl** out, const void* id128, int rank, int world);   /* ncclCommInitRank; collective, blocking */
+BLA_API bla_status bla_dp_rccl_init_all(bla_rccl** out, const int* devices, int world);        /* ncclCommInitAll: out[world] from one thread */
+BLA_API bla_status bla_dp_rccl_group_begin(void);                                               /* ncclGroupStart */
+BLA_API bla_status bla_dp_rccl_group_end(void);                                                 /* ncclGroupEnd */
 BLA_API bla_status bla_dp_rccl_destroy(bla_rccl* c);
 BLA_API bla_status bla_dp_rccl_allreduce_f32(bla_rccl* c, void* stream, float* d_buf, size_t count);   /* in place, SUM, async on stream */
 /* forward + backward into the trainer's gradient bucket, ncclAllReduce of the bucket, params += lr * sum (model/mnist_nn.c:218-315 sharded) */

@@ -222,46 +222,8 @@ def gen_norm():
     np.savez_compressed(os.path.join(GOLD, "norm.npz"), **d)
 
 
-# ---- model/mnist_nn.c:218-315 driven through the reference's matrix.h ---------------
-def ref_mnist_step(params, x_raw, y, intended_colsum):
-    w1, b1, w2, b2, w3, b3 = [np.ascontiguousarray(p, np.float64).copy() for p in params]
-    B = x_raw.shape[1]
-    n0 = w1.shape[1]
-    x = ref.inplace1("matrix_scale", x_raw, C.c_double(np.float32(1) / np.float32(255.0)))   # :218 (1/255.0F)
-
-    def fwd(w, a, b):
-        z = ref.matmul(w, a)                                    # matrix_multiply
-        z = ref.inplace2("matrix_add_tile_columns", z, b)
-        return z
-
-    def colsum(m):
-        if intended_colsum:   # true row sums via the reference's own row_sum of the transpose
-            mt = np.ascontiguousarray(ref.inplace1("matrix_transpose", m))   # keep alive across the call
-            return ref.take(L.matrix_row_sum(ref.mat(mt))).reshape(-1, 1)
-        assert m.shape[0] <= m.shape[1]
-        mc = np.ascontiguousarray(m)
-        return ref.take(L.matrix_col_sum(ref.mat(mc)))
-
-    z1 = fwd(w1, x, b1); a1 = ref.data_fn("relu", z1, z1.size)
-    z2 = fwd(w2, a1, b2); a2 = ref.data_fn("relu", z2, z2.size)
-    z3 = fwd(w3, a2, b3); a3 = ref.data_fn("softmax", z3, z3.shape[0], B)
-    scale = 1 / float(n0)                                        # :260
-    ny = ref.inplace1("matrix_scale", y, C.c_double(-1.0))
-    dz3 = ref.inplace2("matrix_add", a3, ny)
-    dz3 = ref.inplace1("matrix_scale", dz3, C.c_double(scale))
-    dw3 = ref.matmul(dz3, ref.inplace1("matrix_transpose", a2)); db3 = colsum(dz3)
-    da2 = ref.matmul(ref.inplace1("matrix_transpose", w3), dz3)
-    dz2 = ref.inplace2("matrix_multiply_elementwise", (z2 > 0).astype(np.float64), da2)
-    dw2 = ref.matmul(dz2, ref.inplace1("matrix_transpose", a1)); db2 = colsum(dz2)
-    da1 = ref.matmul(ref.inplace1("matrix_transpose", w2), dz2)
-    dz1 = ref.inplace2("matrix_multiply_elementwise", (z1 > 0).astype(np.float64), da1)
-    dw1 = ref.matmul(dz1, ref.inplace1("matrix_transpose", x)); db1 = colsum(dz1)
-    grads = [dw1, db1, dw2, db2, dw3, db3]
-    lr = float(np.float32(-0.02))                                # float epoch_learn_rate, :186
-    new = []
-    for p, g in zip([w1, b1, w2, b2, w3, b3], grads):
-        new.append(ref.inplace2("matrix_add", p, ref.inplace1("matrix_scale", g, C.c_double(lr))))
-    return new, dict(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, a3=a3), grads
+# ---- model/mnist_nn.c:218-315 driven through the reference's matrix.h: ref.mnist_step (oracle/ref.py; bench.py's cpu_baseline leg times the same driver)
+ref_mnist_step = ref.mnist_step
 
 
 def ref_mnist_metrics(a3, y):

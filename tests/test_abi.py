@@ -57,3 +57,37 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 for pat in (r"import\s+oracle", r"from\s+oracle", r"liboracle", r"oracle/", r"ora(32|64)_", r"_ref/libref", r"import\s+ref\b"):
                     assert not re.search(pat, txt), (os.path.join(dp, f), pat)
+
+
+def test_rand_guard_overlapping_threads_keep_the_callers_stream(pkg):
+    """the guard that parks the calling program's libc rand() state around HIP / RCCL calls is process-wide and nestable -- two
+    threads inside the library at once (one host thread per rank) must leave the program's srand(42) stream exactly where it was, whatever
+    the order in which they enter and leave, and whatever is drawn from rand() while a guard is open."""
+    import ctypes
+    import threading
+    libc = ctypes.CDLL("libc.so.6")
+    L = pkg.lib()
+    libc.srand(42); want = [libc.rand() for _ in range(12)]
+    libc.srand(42); got = [libc.rand() for _ in range(4)]
+    a_in, b_in, a_out = threading.Event(), threading.Event(), threading.Event()
+
+    def rank_a():
+        L.bla_rand_guard_enter(); a_in.set()
+        b_in.wait(5)
+        for _ in range(3):
+            libc.rand()          # what the runtime / RCCL would draw while the stream is parked
+        L.bla_rand_guard_leave(); a_out.set()      # A leaves first: B's guard is still open, the stream must stay parked
+
+    def rank_b():
+        a_in.wait(5)
+        L.bla_rand_guard_enter(); b_in.set()
+        a_out.wait(5)
+        libc.rand()
+        L.bla_rand_guard_leave()
+    ta, tb = threading.Thread(target=rank_a), threading.Thread(target=rank_b)
+    ta.start(); tb.start(); ta.join(10); tb.join(10)
+    assert not ta.is_alive() and not tb.is_alive()
+    got += [libc.rand() for _ in range(4)]
+    L.bla_rand_guard_enter(); L.bla_rand_guard_enter(); libc.rand(); L.bla_rand_guard_leave(); libc.rand(); L.bla_rand_guard_leave()   # nested on one thread
+    got += [libc.rand() for _ in range(4)]
+    assert got == want

@@ -296,3 +296,45 @@ def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
         want_dk += ora.matrix_to_kernels(cols.T @ dq, cin, k)
         bound_dk += ora.matrix_to_kernels(np.abs(cols).T @ np.abs(dq), cin, k)
     assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk + 1e-30).all(), shape
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 32, 128, 128, 3, 1),     # SURVEY 8(d) cfg 5 headline: (M,K,N) = (1024,1152,128) per image -- what bench.py's tertiary line times
+                                   (64, 16, 16, 256, 256, 3, 1),     # the second headline shape: (256,2304,256)
+                                   (64, 32, 32, 128, 256, 3, 2)])    # the U-Net's first down-convolution (model/cifar_unet.c:1105): stride 2, data gradient by output parity
+def test_headline_shapes_batch_64_against_the_oracle(dev, ora, shape):
+    """The sizes bench.py reports, at the size it reports them (batch of 64): forward and data gradient of four sampled images against the oracle's
+    conv() / conv_ddx() (lib/conv.c:205-229; stride 2: the adjoint of _im2col), elementwise 1e-5 * (|A||B|); the batch-summed weight gradient against
+    the oracle's per-image products over ALL 64 images."""
+    batch, h, w, cin, cout, k, s = shape
+    ho, wo = ora.out_hw(h, w, s)
+    x = uniform(910, (batch, cin, h, w), -1, 1, F32); kern = uniform(911, (cout, cin, k, k), -0.1, 0.1, F32)
+    del_y = uniform(912, (batch, cout, ho, wo), -1, 1, F32)
+    dx_, dk_, dy_ = dev.to_device(x), dev.to_device(kern), dev.to_device(del_y)
+    out = dev.empty((batch, cout, ho, wo)).fill_bytes(0xFF)
+    call(dev, "bla_conv2d_forward_batched_f32", dx_, dk_, out, batch, h, w, k, cin, cout, s)
+    dkern = dev.empty((cout, cin, k, k)).fill_bytes(0xFF)
+    dxx = dev.empty((batch, cin, h, w)).fill_bytes(0xFF)
+    scratch = dev.empty((cout * cin * k * k,))
+    call(dev, "bla_conv2d_backward_batched_f32", dy_, dx_, dk_, dkern, dxx, scratch, batch, h, w, k, cin, cout, s)
+    got, got_dx = out.numpy(), dxx.numpy()
+    assert np.isfinite(got).all() and np.isfinite(got_dx).all()
+    k64 = kern.astype(np.float64)
+    for b in (0, 21, 42, 63):
+        fw = ora.conv_intended(x[b].astype(np.float64), k64, s)
+        bound = (np.abs(fw["im2col"]) @ np.abs(fw["kmat"])).T.reshape(cout, ho, wo)
+        assert (np.abs(got[b] - fw["output"]) <= 1e-5 * bound + 1e-30).all(), (shape, b)
+        assert np.linalg.norm(got[b] - fw["output"]) <= 1e-5 * np.linalg.norm(fw["output"]), (shape, b)
+        dq = ora.reshape_matrix_channels(del_y[b].astype(np.float64))
+        b2 = (np.abs(dq) @ np.abs(fw["kmat"]).T).max() * k * k
+        want_dx = ora.conv_ddx_intended(del_y[b].astype(np.float64), fw["im2col"], fw["kmat"], cin, k)["del_x"] if s == 1 else \
+            ora.col2im_adjoint(dq @ fw["kmat"].T, cin, h, w, k, s)
+        assert (np.abs(got_dx[b] - want_dx) <= 1e-5 * b2).all(), (shape, b)
+        assert np.linalg.norm(got_dx[b] - want_dx) <= 1e-5 * np.linalg.norm(want_dx), (shape, b)
+    want_dk = np.zeros((cout, cin, k, k)); bound_dk = np.zeros((cout, cin, k, k))
+    for b in range(batch):
+        cols = ora.im2col(x[b].astype(np.float64), k, s)
+        dq = ora.reshape_matrix_channels(del_y[b].astype(np.float64))
+        want_dk += ora.matrix_to_kernels(cols.T @ dq, cin, k)
+        bound_dk += ora.matrix_to_kernels(np.abs(cols).T @ np.abs(dq), cin, k)
+    assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk + 1e-30).all(), shape
+    assert np.linalg.norm(dkern.numpy() - want_dk) <= 1e-5 * np.linalg.norm(want_dk), shape
