@@ -378,6 +378,7 @@ struct ConvArgs {
 	float* ep_out2 = nullptr;
 	int ep_bias_stride = 0;      // batched tiled forward only: bias set per image
 	bool ep_fused_tiled = false; // the tiled (padded-copy, half-slab) forward kernel applies the epilogue itself
+	bool a_tapmajor = false;     // A is already [M][(tap, channel)] (the unpadded tiled kernel's order): the caller took plan_forward's word for the path
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -691,6 +692,80 @@ static bla_status get_padded_tables(hipStream_t s, const ConvGeom& g, const int2
 	return BLA_OK;
 }
 
+// ---- tiled gather straight from the image (no padded copy), stride 1: gather modes 5 / 6 of bla_gemm.hip -------------------------------------
+// The contraction of the forward pass / data gradient runs TAP-MAJOR there, k = t * C + c: a 16-deep slab is 16 channels of one tap, so the tap's
+// shift (dy, dx) is one scalar per slab and the kernel can do by itself what the zero padding of the copy did (rows outside the image from a
+// zero word, the one element beyond a row's end patched in LDS).  The kernel matrix [M][(c, t)] is re-ordered to [M][(t, c)] by one small launch.
+__global__ void __launch_bounds__(kThreads) tapmajor_kernels_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int c_n, int kk) {
+	const int kdim = c_n * kk, total = rows * kdim;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {   // e = (m, t, c): coalesced writes
+		const int m = e / kdim, r = e - m * kdim, t = r / c_n, c = r - t * c_n;
+		out[e] = a[(size_t)m * kdim + c * kk + t];
+	}
+}
+// the data gradient's kernel matrix, flipped and tap-major in one pass: out[c][t * F + f] = kern[f][c][k*k - 1 - t]  (flip_kernels_kernel, then tapmajor_kernels_kernel)
+__global__ void __launch_bounds__(kThreads) flip_tapmajor_kernels_kernel(const float* __restrict__ kern, float* __restrict__ out, int f_n, int c_n, int k) {
+	const int kk = k * k, kdim = f_n * kk, total = c_n * kdim;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		const int c = e / kdim, r = e - c * kdim, t = r / f_n, f = r - t * f_n;
+		out[e] = kern[((size_t)f * c_n + c) * kk + (kk - 1 - t)];
+	}
+}
+// slab s of the tap-major contraction (C / 16 slabs per tap): {c0 * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8}
+__global__ void __launch_bounds__(256) unpadded_slab_table_kernel(int2* tab, ConvGeom g) {
+	const int e = blockIdx.x * blockDim.x + threadIdx.x, per_tap = g.c / 16;
+	if (e >= g.k * g.k * per_tap) return;
+	const int t = e / per_tap, c0 = (e - t * per_tap) * 16, dy = t / g.k - g.pt, dx = t % g.k - g.pl;
+	tab[e] = make_int2(c0 * g.h * g.w + dy * g.w + dx, (dy & 255) | ((dx & 255) << 8));
+}
+// weight gradient: tap m = (c, p, q) -> {c * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8};  per 16 pixels of an image (one 16-deep slab of the
+// contraction) one int4: i | j << 16 of the first pixel of each of its four chunks
+__global__ void __launch_bounds__(256) unpadded_wgrad_tables_kernel(int2* taps, int* pix, ConvGeom g) {
+	const int e = blockIdx.x * blockDim.x + threadIdx.x, kk = g.k * g.k;
+	if (e < g.c * kk) { const int c = e / kk, t = e - c * kk, dy = t / g.k - g.pt, dx = t % g.k - g.pl; taps[e] = make_int2(c * g.h * g.w + dy * g.w + dx, (dy & 255) | ((dx & 255) << 8)); }
+	if (e < g.h * g.w / 4) { const int r = e * 4, i = r / g.w, j = r - i * g.w; pix[e] = i | (j << 16); }
+}
+struct UnpaddedTables { int device; ConvGeom g; int2* slabs; int2* taps; int2* pix; };
+static std::vector<UnpaddedTables> g_unpadded;
+
+static bla_status get_unpadded_tables(hipStream_t s, const ConvGeom& g, const int2** slabs, const int2** taps, const int2** pix) {
+	std::lock_guard<std::mutex> lk(g_table_mu);
+	const int dev = ctx().device;
+	for (const UnpaddedTables& e : g_unpadded) {
+		const ConvGeom& t = e.g;
+		if (e.device == dev && t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c && t.pt == g.pt && t.pl == g.pl) {
+			if (slabs) *slabs = e.slabs;
+			if (taps) *taps = e.taps;
+			if (pix) *pix = e.pix;
+			return BLA_OK;
+		}
+	}
+	bla_status st = table_build_allowed(s);
+	if (st) return st;
+	UnpaddedTables n = {dev, g, nullptr, nullptr, nullptr};
+	const int ns = g.k * g.k * ((g.c + 15) / 16), nt = g.c * g.k * g.k, np = g.h * g.w;
+	BLA_HIP(hipMalloc((void**)&n.slabs, (size_t)ns * sizeof(int2)));
+	BLA_HIP(hipMalloc((void**)&n.taps, (size_t)nt * sizeof(int2)));
+	BLA_HIP(hipMalloc((void**)&n.pix, ((size_t)np / 4 + 4) * sizeof(int)));   // (read as int4 per 16 pixels: 16-byte aligned by hipMalloc)
+	if (g.c % 16 == 0) hipLaunchKernelGGL(unpadded_slab_table_kernel, dim3((ns + 255) / 256), dim3(256), 0, ctx().stream, n.slabs, g);
+	const int cnt = nt > np ? nt : np;
+	hipLaunchKernelGGL(unpadded_wgrad_tables_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx().stream, n.taps, (int*)n.pix, g);
+	BLA_HIP(hipGetLastError());
+	BLA_HIP(hipStreamSynchronize(ctx().stream));
+	g_unpadded.push_back(n);
+	if (slabs) *slabs = n.slabs;
+	if (taps) *taps = n.taps;
+	if (pix) *pix = n.pix;
+	return BLA_OK;
+}
+// geometry the unpadded kernels take: stride 1, shifts of at most one column (k <= 3), rows of whole 16-byte chunks.  BLA_CONV_UNPADDED=0 keeps the padded copy.
+static bool unpadded_geometry(const ConvGeom& g) {
+	static const bool off = [] { const char* e = getenv("BLA_CONV_UNPADDED"); return e && e[0] == '0'; }();
+	// (rows of at least four 16-byte chunks: the kernels' counted wait needs every DMA instruction to keep a lane that is not a row end; the 8- and
+	// 4-pixel-wide maps stay on the padded copy, which is a few KB there)
+	return !off && g.s == 1 && g.k <= 3 && g.w % 4 == 0 && g.w >= 16 && g.ho == g.h && g.wo == g.w && g.pl <= 1 && g.k - 1 - g.pl <= 1 && g.h < 32768 && g.w < 32768;
+}
+
 // A batch large enough to fill the chip with 128x128 tiles goes to the LDS-tiled gather kernel (bla_gemm.hip: same pipeline as the
 // dense GEMM, the B slab fetched by 4-byte direct-to-LDS loads from computed addresses); small batches and odd shapes stay on the
 // 32x32 wave-split-K gather kernel above.
@@ -704,6 +779,20 @@ static bool use_tiled_gather(const ConvArgs& a, int batch, int mode) {
 	// applies (8x8 and 4x4 maps of a batch: 64 and 16 tiles)
 	if (mode == 1) return a.K % 16 == 0 && (tiles >= 128 || (a.M % 128 == 0 && cols % 128 == 0 && a.g.wo % 4 == 0 && tiles * gather3_splits(a.M, (int)cols, a.K) >= 128));
 	return a.K % 16 == 0 && kk >= 1024 && tiles * batch >= 128;   // a.K = output pixels per image here
+}
+
+// Which kernel a forward-shaped pass (forward, stride-1 data gradient) runs on, decided in ONE place: conv2d_forward asks it whether the tile store
+// will apply the epilogue, launch_implicit follows it.
+enum FwdPath { FWD_WSK = 0, FWD_TILED_CHECKED = 1, FWD_TILED_PADDED = 3, FWD_TILED_UNPADDED = 5 };
+struct FwdPlan { FwdPath path; bool fuses_epilogue; };
+static FwdPlan plan_forward(const ConvArgs& a, int batch) {
+	if (!use_tiled_gather(a, batch, 1)) return FwdPlan{FWD_WSK, batch == 1};   // (the 32x32 kernel applies one bias set where it stores: a single image)
+	const PaddedGeom pg = padded_geom(a.g);
+	const bool fits32 = (size_t)batch * a.g.c * pg.plane_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
+	if (!fits32 || a.g.wo % 4 != 0) return FwdPlan{FWD_TILED_CHECKED, false};
+	const bool fuses = gather3_fuses_epilogue(a.M, a.N * batch, a.K);
+	if (unpadded_geometry(a.g) && a.g.c % 16 == 0 && gather_whole_tiles(5, a.M, a.N * batch)) return FwdPlan{FWD_TILED_UNPADDED, fuses};
+	return FwdPlan{FWD_TILED_PADDED, fuses};
 }
 
 // tiling / K-splitting of the 32x32 wave-split-K gather kernel for one pass; a.batch and the strides are set
@@ -734,7 +823,32 @@ static bla_status plan_wsk_gather(ConvArgs& a, int batch, size_t* slab_bytes, di
 template <int MODE>
 static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, size_t img_stride = 0, size_t out_stride = 0, size_t a_stride = 0) {
 	a.batch = batch; a.img_stride = img_stride; a.out_stride = out_stride; a.a_stride = a_stride;
-	if (use_tiled_gather(a, batch, MODE == CONV_FWD ? 1 : 2)) {
+	const FwdPlan plan = MODE == CONV_FWD ? plan_forward(a, batch) : FwdPlan{FWD_WSK, false};
+	// ep_fused_tiled is conv2d_forward's word that the tile store applies the adds: it took that from the same plan (no second copy of the predicate)
+	BLA_REQUIRE(!a.ep_fused_tiled || (plan.fuses_epilogue && plan.path != FWD_WSK), BLA_ERR_INVALID, "internal: a fused epilogue was planned for a path that has none");
+	BLA_REQUIRE(!a.a_tapmajor || plan.path == FWD_TILED_UNPADDED, BLA_ERR_INVALID, "internal: tap-major kernels handed to a path that contracts channel-major");
+	if (MODE == CONV_FWD && plan.path == FWD_TILED_UNPADDED) {
+		// straight from the image: the kernel matrix goes tap-major into the workspace ([slabs][kernels]), then one gathered product
+		const int splits5 = gather3_splits(a.M, a.N * batch, a.K);
+		const size_t slab_bytes = splits5 > 1 ? ((size_t)splits5 * a.M * a.N * batch * sizeof(float) + 255) / 256 * 256 : 0;
+		void* ws;
+		bla_status st = ensure_workspace(slab_bytes + (a.a_tapmajor ? 0 : (size_t)a.M * a.K * sizeof(float)) + 64, &ws);
+		if (st) return st;
+		const float* a5 = a.A;
+		const int2* slabs;
+		st = get_unpadded_tables(s, a.g, &slabs, nullptr, nullptr);
+		if (st) return st;
+		if (!a.a_tapmajor) {
+			float* re = (float*)((char*)ws + slab_bytes);
+			hipLaunchKernelGGL(tapmajor_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, re, a.M, a.g.c, a.g.k * a.g.k);
+			BLA_HIP(hipGetLastError());
+			a5 = re;
+		}
+		const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
+		return gather_gemm(s, 5, batch, a.M, a.N * batch, a.K, a5, a.K, a.out, a.ldo, a.img, slabs, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
+		                   a.ep_fused_tiled ? &gep : nullptr);
+	}
+	if (MODE == CONV_FWD ? plan.path != FWD_WSK : use_tiled_gather(a, batch, 2)) {
 		const int2* ptab;
 		bla_status st = get_pixel_table(s, a.g, &ptab);
 		if (st) return st;
@@ -742,7 +856,7 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		const PaddedGeom pg = padded_geom(a.g);
 		const size_t copy_floats = (size_t)batch * a.g.c * pg.plane_floats;
 		const bool fits32 = copy_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
-		if (MODE == CONV_FWD && fits32 && a.g.wo % 4 == 0) {
+		if (MODE == CONV_FWD && plan.path == FWD_TILED_PADDED) {
 			// pad (and split by stride parity) once, then the B slab is fetched with the same 16-byte DMA as a dense operand
 			const int splits3 = gather3_splits(a.M, a.N * batch, a.K);
 			const size_t slab_bytes = splits3 > 1 ? ((size_t)splits3 * a.M * a.N * batch * sizeof(float) + 255) / 256 * 256 : 0;
@@ -761,6 +875,13 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
+		if (MODE == CONV_WGRAD && fits32 && a.g.wo % 4 == 0 && a.N % 4 == 0 && unpadded_geometry(a.g) && gather_whole_tiles(6, a.N, a.M)) {
+			// transposed product straight from the image: taps are the rows, both operands stream in 16-byte chunks, no padded copy
+			const int2 *taps, *pix;
+			st = get_unpadded_tables(s, a.g, nullptr, &taps, &pix);
+			if (st) return st;
+			return gather_gemm(s, 6, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, pix, taps, a.g.h, a.g.w, a.K, (int)img_stride);
+		}
 		if (MODE == CONV_WGRAD && fits32 && a.g.wo % 4 == 0 && a.N % 4 == 0) {
 			// transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const size_t slab_bytes = ((size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float) + 255) / 256 * 256;
@@ -1016,15 +1137,10 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
 	const bool ep = ep_bias || ep_out2;
 	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
-	if (ep && (batch > 1 || use_tiled_gather(a, batch, 1))) {
-		// the half-slab forward kernel applies the adds where it stores its tiles (one pass over K, whole tiles); the other tiled kernels carry no
-		// epilogue and the 32x32 kernel's knows one bias set: one pass behind them
-		const PaddedGeom pg = padded_geom(a.g);
-		const bool fits32 = (size_t)batch * a.g.c * pg.plane_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
-		if (use_tiled_gather(a, batch, 1) && fits32 && a.g.wo % 4 == 0 && gather3_fuses_epilogue(a.M, a.N * batch, a.K)) {
-			a.ep_bias = ep_bias; a.ep_bias_stride = ep_bias_stride; a.ep_add = ep_add; a.ep_out2 = ep_out2; a.ep_fused_tiled = true;
-			return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
-		}
+	const FwdPlan plan = plan_forward(a, batch);
+	if (ep && !plan.fuses_epilogue) {
+		// the half-slab forward kernels apply the adds where they store their tiles (one pass over K, whole tiles) and the 32x32 kernel does for a single
+		// image; the other kernels carry no epilogue (the 32x32 kernel's knows one bias set): one pass behind them
 		st = launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
 		if (st) return st;
 		const size_t total = (size_t)batch * f_n * a.N;
@@ -1032,7 +1148,8 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 		BLA_HIP(hipGetLastError());
 		return BLA_OK;
 	}
-	a.ep_bias = ep_bias; a.ep_add = ep_add; a.ep_out2 = ep_out2;
+	a.ep_bias = ep_bias; a.ep_bias_stride = ep_bias_stride; a.ep_add = ep_add; a.ep_out2 = ep_out2;
+	a.ep_fused_tiled = ep && plan.path != FWD_WSK;
 	return launch_implicit<CONV_FWD>(s, a, batch, (size_t)c_in * h * w, (size_t)f_n * gm.ho * gm.wo, 0);
 }
 
@@ -1214,7 +1331,15 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
 		if (parity_dgrad_applies(batch, h, w, k, c_in, f_n, stride, gm)) return conv2d_backward_parity(s, d_del_y, d_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, gm);
 		int total = f_n * c_in * k * k;
-		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+		bool tapmajor = false;
+		if (stride == 1) {   // will the stride-1 pass below run straight from del_y (tap-major contraction)?  Then the flipped kernels are written in that order at once
+			ConvArgs q;
+			q.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
+			q.A = d_scratch; q.lda = k * k * f_n; q.M = c_in; q.N = h * w; q.K = k * k * f_n;
+			tapmajor = plan_forward(q, batch).path == FWD_TILED_UNPADDED;
+		}
+		if (tapmajor) hipLaunchKernelGGL(flip_tapmajor_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+		else hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
 		BLA_HIP(hipGetLastError());
 		// Stride s > 1 (the intended adjoint; the reference is undefined there): the same stride-1 convolution over del_y with s-1 zeros
 		// put between its pixels, [F][(Ho-1)s+1][(Wo-1)s+1] -- the U-Net's three down-convolutions (model/cifar_unet.c:1105,1111,1115).
@@ -1237,6 +1362,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
+		a.a_tapmajor = tapmajor;
 		st = launch_implicit<CONV_FWD>(s, a, batch, src_sz, x_sz, 0);
 		if (st) return st;
 	}

@@ -36,7 +36,7 @@ using namespace bla;
 
 namespace {
 constexpr int kMaxWorld = 16;
-constexpr long long kTimeoutTicks = 400000000LL;   // wall_clock64 runs at 100 MHz: 4 s
+constexpr long long kTicksPerMs = 100000LL;        // wall_clock64 runs at 100 MHz; the wait for a peer gives up after BLA_DP_TIMEOUT_MS (default 4000)
 
 struct DpKernelArgs {
 	const float* src[kMaxWorld];          // bucket of rank r for this parity (own: local pointer)
@@ -55,6 +55,7 @@ struct DpKernelArgs {
 	unsigned* peer_flags_b[kMaxWorld];    // second flag array ("my reduced slice is ready") in rank p's memory
 	unsigned* flags_b;
 	unsigned per4;                        // float4 groups per slice: slice r = [r * per4, min((r + 1) * per4, n4))
+	long long timeout_ticks;
 };
 
 __device__ __forceinline__ float4 load16_nt(const float* base, size_t i4) {
@@ -82,12 +83,12 @@ __device__ __forceinline__ void deliver(const DpKernelArgs& a, unsigned i, float
 }
 
 // wait until flags[r] has reached `epoch` for every r < world (threads r < world poll); returns false on time-out
-__device__ __forceinline__ bool wait_flags(const unsigned* flags, int world, int rank, unsigned epoch, int* s_fail) {
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int world, int rank, unsigned epoch, int* s_fail, long long timeout_ticks) {
 	if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {   // (a rank's own data is ordered by its stream: no flag to itself)
 		const long long t0 = wall_clock64();
 		while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
 			__builtin_amdgcn_s_sleep(4);
-			if (wall_clock64() - t0 > kTimeoutTicks) { *s_fail = 1; break; }
+			if (wall_clock64() - t0 > timeout_ticks) { *s_fail = 1; break; }
 		}
 	}
 	__syncthreads();
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 	__syncthreads();
 	if (blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)   // (the system-scope release is the fence)
 		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	bool ok = wait_flags(a.flags, a.world, a.rank, epoch, &s_fail);
+	bool ok = wait_flags(a.flags, a.world, a.rank, epoch, &s_fail, a.timeout_ticks);
 	// phase A: my slice of every bucket, summed in rank order -> reduced buffer (for the peers) and my own out / target
 	const unsigned lo = a.rank * a.per4, hi = min(lo + a.per4, a.n4);
 	if (ok) {
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 			__hip_atomic_store(a.peer_flags_b[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	// phase B: the peers' reduced slices
-	ok = wait_flags(a.flags_b, a.world, a.rank, epoch, &s_fail) && ok;
+	ok = wait_flags(a.flags_b, a.world, a.rank, epoch, &s_fail, a.timeout_ticks) && ok;
 	if (ok) {
 		const unsigned rest = a.n4 - (hi - lo);   // groups owned by the peers
 		for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < rest; j += gridDim.x * 256) {
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 		const long long t0 = wall_clock64();
 		while ((int)(__hip_atomic_load(a.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
 			__builtin_amdgcn_s_sleep(4);
-			if (wall_clock64() - t0 > kTimeoutTicks) { s_fail = 1; break; }
+			if (wall_clock64() - t0 > a.timeout_ticks) { s_fail = 1; break; }
 		}
 	}
 	__syncthreads();
@@ -240,6 +241,8 @@ struct bla_dp {
 	void* peer_flags[kMaxWorld];
 	bool peer_ipc[kMaxWorld];    // opened through hipIpcOpenMemHandle (to be closed)
 	bool connected;
+	unsigned resident_blocks;    // workgroups of the two-shot kernel this device holds at once (occupancy x CUs), measured at create
+	long long timeout_ticks;
 	unsigned long long steps;    // data-parallel steps issued through this object: the trainers take their bucket parity from here
 };
 
@@ -299,6 +302,14 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	dp->peer[rank] = dp->base; dp->peer_flags[rank] = dp->flags;
 	dp->connected = world == 1;
 	dp->steps = 0;
+	// The two-shot kernel's second phase waits for workgroups of the same launch (here and on the peers): its grid must be resident at once.  What
+	// "at once" allows is asked of the runtime (occupancy of that kernel x CUs), not assumed.
+	int occ = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dp_allreduce_twoshot_kernel, 256, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }
+	dp->resident_blocks = (unsigned)occ * (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+	const char* tmo = getenv("BLA_DP_TIMEOUT_MS");
+	const long long ms = tmo && atoll(tmo) > 0 ? atoll(tmo) : 4000;
+	dp->timeout_ticks = ms * kTicksPerMs;
 	*out = dp;
 	return BLA_OK;
 }
@@ -393,6 +404,7 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 	a.out = d_out; a.target = d_target; a.alpha = alpha;
 	a.n4 = (unsigned)((dp->count + 3) / 4); a.count = (unsigned)dp->count;
 	a.world = dp->world; a.rank = dp->rank;
+	a.timeout_ticks = dp->timeout_ticks;
 	unsigned cus = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
 	// Every workgroup of an exchange launch spins until the peers' launches have shown up, so all launches of a group must be resident
 	// at once.  One rank per GPU: always true.  Several ranks REHEARSING on one GPU (tests, BLA_BENCH_SHARE_GPU) share its workgroup
@@ -409,7 +421,10 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 		a.per4 = dp->per4;
 		// the second phase waits for workgroups of this same launch (here and on the peers): keep the grid fully resident
 		unsigned blocks = (a.n4 - a.per4 + 255) / 256;
-		const unsigned cap = max_blocks ? cus : (cus / 2 < 128 ? (cus / 2 ? cus / 2 : 1) : 128);
+		// a quarter of what the device holds at once, at most 128 (more workgroups than that do not make a 0.94 MB exchange faster): the grid stays resident
+		// beside whatever else the stream's neighbours run.  BLA_DP_MAX_BLOCKS overrides (several ranks rehearsing on ONE device share its slots).
+		const unsigned quarter = dp->resident_blocks / 4 ? dp->resident_blocks / 4 : 1;
+		const unsigned cap = max_blocks ? cus : (quarter < 128 ? quarter : 128);
 		if (blocks > cap) blocks = cap;
 		if (blocks < 1) blocks = 1;
 		hipLaunchKernelGGL(dp_allreduce_twoshot_kernel, dim3(blocks), dim3(256), 0, pick_stream(stream), a);
@@ -434,5 +449,16 @@ bla_status bla_dp_status(bla_dp* dp, int* status) {
 	*status = (int)s[2];
 	return BLA_OK;
 }
+
+/* BLA_ERR_TIMEOUT when a wait for a peer's flag has timed out in some earlier exchange (nothing was delivered by that exchange: out / target keep
+ * what they held), else BLA_OK.  Synchronises the device. */
+bla_status bla_dp_check(bla_dp* dp) {
+	int st = 0;
+	bla_status r = bla_dp_status(dp, &st);
+	if (r) return r;
+	BLA_REQUIRE(st == 0, BLA_ERR_TIMEOUT, "a rank never arrived at the gradient exchange: the wait for its flag timed out (BLA_DP_TIMEOUT_MS) and the sums were not delivered");
+	return BLA_OK;
+}
+int bla_dp_resident_blocks(const bla_dp* dp) { return dp ? (int)dp->resident_blocks : 0; }
 
 }  // extern "C"

@@ -262,6 +262,7 @@ const char* bla_status_string(bla_status s) {
 		case BLA_ERR_NO_DEVICE: return "no device / not initialised";
 		case BLA_ERR_HIP: return "HIP runtime error";
 		case BLA_ERR_UNDEFINED: return "undefined in the reference";
+		case BLA_ERR_TIMEOUT: return "a rank never arrived at the exchange";
 		default: return "unknown status";
 	}
 }

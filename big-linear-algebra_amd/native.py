@@ -130,6 +130,7 @@ SIGNATURES = {
     "bla_dp_allreduce_f32": (_I, [_VP, _VP, _I, _VP, _VP, _F]), "bla_dp_status": (_I, [_VP, C.POINTER(_I)]),
     "bla_dp_rccl_unique_id": (_I, [_VP]), "bla_dp_rccl_init": (_I, [C.POINTER(_VP), _VP, _I, _I]), "bla_dp_rccl_destroy": (_I, [_VP]),
     "bla_dp_rccl_allreduce_f32": (_I, [_VP, _VP, _VP, _SZ]), "bla_mnist_nn_dp_step_rccl": (_I, [_VP, _VP, _VP, _F, _I]),
+    "bla_dp_check": (_I, [_VP]), "bla_dp_resident_blocks": (_I, [_VP]),
     "bla_dp_rccl_available": (_I, []), "bla_dp_rccl_init_all": (_I, [C.POINTER(_VP), C.POINTER(_I), _I]), "bla_dp_rccl_group_begin": (_I, []),
     "bla_dp_rccl_group_end": (_I, []), "bla_rand_guard_enter": (None, []), "bla_rand_guard_leave": (None, []),
     "bla_mnist_nn_dp_step": (_I, [_VP, _VP, _VP, _F, _I]), "bla_mnist_nn_dp_step_direct": (_I, [_VP, _VP, _VP, _F, _I]),

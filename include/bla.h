@@ -42,7 +42,8 @@ enum {
 	BLA_ERR_SHAPE = 2,     /* operand shapes do not conform */
 	BLA_ERR_NO_DEVICE = 3, /* no usable gfx950 device / runtime not initialised */
 	BLA_ERR_HIP = 4,       /* a HIP runtime call failed; see bla_last_error() */
-	BLA_ERR_UNDEFINED = 5  /* the reference itself is undefined here (e.g. col2im with stride != 1) */
+	BLA_ERR_UNDEFINED = 5, /* the reference itself is undefined here (e.g. col2im with stride != 1) */
+	BLA_ERR_TIMEOUT = 6    /* a rank of the gradient exchange never arrived (bla_dp_check) */
 };
 
 /* ---- runtime -------------------------------------------------------------- */
@@ -482,6 +483,12 @@ BLA_API size_t bla_dp_count(const bla_dp* dp);
 BLA_API bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha);
 /* *status = 0 healthy, 1 = some earlier exchange gave up waiting for a peer (4 s) and skipped its sums; synchronises */
 BLA_API bla_status bla_dp_status(bla_dp* dp, int* status);
+/* the same as a return code: BLA_ERR_TIMEOUT when some earlier exchange gave up waiting (BLA_DP_TIMEOUT_MS, default 4000) -- that exchange delivered
+ * NOTHING (out / target keep what they held; never zeros in place of sums); the exchange object is then out of step with its peers: destroy it */
+BLA_API bla_status bla_dp_check(bla_dp* dp);
+/* workgroups of the two-shot exchange kernel this device holds at once (occupancy x CUs, asked of the runtime at create): its grid is capped at a
+ * quarter of that (at most 128), so that the phase that waits for workgroups of the same launch is always fully resident */
+BLA_API int bla_dp_resident_blocks(const bla_dp* dp);
 /* forward + backward + exchange + update of one data-parallel step as one graph launch (BLA_COLSUM_INTENDED only) */
 BLA_API bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, float lr, int colsum_mode);
 /* the same step issued directly on the stream (seven launches from one host call); may be mixed with the graph form */

@@ -338,3 +338,16 @@ def test_headline_shapes_batch_64_against_the_oracle(dev, ora, shape):
         bound_dk += ora.matrix_to_kernels(np.abs(cols).T @ np.abs(dq), cin, k)
     assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk + 1e-30).all(), shape
     assert np.linalg.norm(dkern.numpy() - want_dk) <= 1e-5 * np.linalg.norm(want_dk), shape
+
+
+@pytest.mark.parametrize("shape", [(64, 16, 16, 128, 256, 1, 1),     # 1x1 kernels on the tiled kernels (the U-Net's residual convolutions, model/cifar_unet.c:1062-1066): no shifts at all
+                                   (64, 8, 8, 128, 128, 2, 1),       # even kernel: the SAME padding sits at the bottom / right only (pt = pl = 0), shifts 0 and +1
+                                   (32, 8, 16, 128, 128, 3, 1),      # rows longer than the map is high; few tiles: the taps cut over workgroups
+                                   (16, 9, 32, 128, 128, 3, 1),      # 288 pixels per image: 128-pixel tiles straddle two images
+                                   (128, 4, 8, 128, 128, 3, 1),      # rows of two chunks: every chunk is a row end
+                                   (8, 32, 32, 256, 128, 3, 1)])     # concatenated inputs (256 -> 128, the up-sampling blocks' first convolution) on 64 tiles
+def test_tiled_gather_straight_from_the_image(dev, ora, shape):
+    """Stride-1 convolutions whose whole 128-wide tiles run WITHOUT a padded copy (gather modes 5 / 6: tap-major contraction, rows outside the image from a
+    zero word, the element beyond a row's end patched in LDS): the geometries that stress exactly that -- 1x1 and even kernels, tiles that straddle
+    images, maps whose rows are one or two 16-byte chunks -- against the oracle like the shapes above (same checks, same tolerances)."""
+    test_batched_conv_tiled_gather_kernel(dev, ora, shape)

@@ -158,3 +158,59 @@ def test_single_rank_exchange_is_the_plain_step(dev):
                 nn.train_step()
         outs.append(mn.flatten_params(nn.get_params()))
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("algo", ["oneshot", "twoshot"])
+def test_absent_rank_times_out_and_delivers_nothing(algo):
+    """A rank that never arrives at the exchange: the waiting rank's kernel gives up after BLA_DP_TIMEOUT_MS, raises the status word,
+    bla_dp_check returns BLA_ERR_TIMEOUT, and NOTHING is delivered -- `out` and `target` keep their sentinels (never zeros in place of sums).  In a child
+    process: the time-out and the algorithm are read from the environment when the exchange object is created."""
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+from __graft_entry__ import load_pkg
+bla = load_pkg(); bla.init(0); L = bla.lib(); chk = bla.native.check
+count = 10007
+ctxs, dps = [], []
+for r in range(2):                                   # two ranks of one process, each in its own context (own stream) on the one GPU
+    c = C.c_void_p(); chk(L.bla_context_create(C.byref(c), 0)); ctxs.append(c)
+    chk(L.bla_context_set_current(c))
+    d = C.c_void_p(); chk(L.bla_dp_create(C.byref(d), r, 2, count)); dps.append(d)
+blobs = (C.c_char * 512)()
+for r in range(2):
+    chk(L.bla_dp_export(dps[r], C.byref(blobs, 256 * r)))
+for r in range(2):
+    chk(L.bla_context_set_current(ctxs[r])); chk(L.bla_dp_connect(dps[r], blobs))
+assert 128 <= L.bla_dp_resident_blocks(dps[0]) <= 65536
+chk(L.bla_context_set_current(ctxs[0]))              # rank 0 exchanges; rank 1 never does
+tgt = bla.to_device(np.full(count, -3.25, np.float32)); out = bla.to_device(np.full(count, 7.5, np.float32))
+chk(L.bla_memset(L.bla_dp_bucket(dps[0], 0), 0, count * 4, None))
+chk(L.bla_dp_allreduce_f32(dps[0], None, 0, out.ptr, tgt.ptr, C.c_float(0.5)))
+st = C.c_int(); chk(L.bla_dp_status(dps[0], C.byref(st)))
+rc = L.bla_dp_check(dps[0])
+print("RESULT", st.value, rc, bool((out.numpy() == 7.5).all()), bool((tgt.numpy() == -3.25).all()), L.bla_last_error().decode()[:60])
+''' % ROOT
+    env = dict(os.environ, BLA_DP_TIMEOUT_MS="300", BLA_DP_ALGO=algo, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split(None, 5)
+    assert line[1] == "1" and line[2] == "6" and line[3] == "True" and line[4] == "True", r.stdout      # status word 1, BLA_ERR_TIMEOUT = 6, sentinels intact
+    assert "never arrived" in line[5]
+
+
+def test_rccl_init_all_single_thread(dev):
+    """ADVICE r2: ONE host thread creating the communicators of all its ranks must not block in ncclCommInitRank -- bla_dp_rccl_init_all (ncclCommInitAll)
+    plus the group bracket around the ranks' collectives.  The pool has one-GPU boxes and RCCL refuses duplicate devices, so world = 1 is what can
+    execute here; the same calls with world = 8 are what examples/ and a multi-GPU host would issue."""
+    import ctypes as C
+    L = dev.lib(); chk = dev.native.check
+    assert L.bla_dp_rccl_available() == 1
+    comms = (C.c_void_p * 1)(); devs = (C.c_int * 1)(0)
+    chk(L.bla_dp_rccl_init_all(comms, devs, 1))
+    g = dev.to_device(uniform(6, (4099,), -1, 1, np.float32))
+    chk(L.bla_dp_rccl_group_begin())
+    chk(L.bla_dp_rccl_allreduce_f32(comms[0], None, g.ptr, 4099))
+    chk(L.bla_dp_rccl_group_end())
+    dev.sync()
+    assert np.array_equal(g.numpy(), uniform(6, (4099,), -1, 1, np.float32))
+    chk(L.bla_dp_rccl_destroy(comms[0]))

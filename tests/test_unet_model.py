@@ -252,8 +252,9 @@ def test_reference_constants_against_the_oracle(pkg, ora):
     epsilon 0 (lib/norm.c:3,36-44), so this network amplifies rounding.  The reference's OWN loops evaluated in float (same order of
     additions, float arithmetic: the fp32 instantiation of the pinned oracle) sit 1.7e-4 (prediction) and 2e-3 .. 3.5e-3 (gradient tensors, normwise)
     from their fp64 evaluation on these inputs.  The device computes in fp32 with fp64 accumulation inside the norms and a different order of
-    additions inside the products, so it must land inside that same neighbourhood: prediction <= the fp32 reference's distance, every gradient
-    tensor <= 1.5 x the fp32 reference's distance for that tensor.  (An indexing or wiring error is an O(1) distance.)"""
+    additions inside the products, so it must land inside that same neighbourhood: prediction <= the fp32 reference's distance (measured: 2.2e-5, an
+    eighth of it), every gradient tensor <= the fp32 reference's distance for that tensor (measured: at most 0.31 of it).  (An indexing or wiring
+    error is an O(1) distance.)"""
     from unet_refconst import CFG, tensor_list, make_params, make_inputs
     pkg.init(0)
     L = pkg.lib(); chk = pkg.native.check
@@ -289,5 +290,5 @@ def test_reference_constants_against_the_oracle(pkg, ora):
         e = np.linalg.norm(g - w) / np.linalg.norm(w)
         if e / d32 > worst[1]:
             worst = (name, e / d32, e)
-        assert e <= 1.5 * d32, f"{name}: {e:.3e} from the fp64 oracle, the fp32 reference {d32:.3e}"
+        assert e <= d32, f"{name}: {e:.3e} from the fp64 oracle, the fp32 reference {d32:.3e}"
     print(f"worst gradient tensor relative to the fp32 reference's own distance: {worst[0]} {worst[2]:.2e} = {worst[1]:.2f} x")

@@ -23,7 +23,8 @@ def timeit(fn, iters=30):
     ms = C.c_float(); chk(L.bla_event_elapsed_ms(e0, e1, C.byref(ms)))
     return ms.value / iters * 1e-3
 
-for (h, cin, cout, k, s) in [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256, 256, 3, 1), (4, 256, 256, 3, 1), (32, 3, 128, 3, 1), (32, 256, 128, 3, 1), (32, 128, 256, 3, 2)]:
+single = [] if os.environ.get("CONV_BENCH_BATCH_ONLY") == "1" else [(32, 128, 128, 3, 1), (16, 256, 256, 3, 1), (8, 256, 256, 3, 1), (4, 256, 256, 3, 1), (32, 3, 128, 3, 1), (32, 256, 128, 3, 1), (32, 128, 256, 3, 2)]
+for (h, cin, cout, k, s) in single:
     w = h; ho = -(-h // s); hw = ho * ho; kkc = k * k * cin
     x = bla.to_device(rng.uniform(-1, 1, (cin, h, w)).astype(np.float32)); kern = bla.to_device(rng.uniform(-.1, .1, (cout, cin, k, k)).astype(np.float32))
     dy = bla.to_device(rng.uniform(-1, 1, (cout, ho, ho)).astype(np.float32))
