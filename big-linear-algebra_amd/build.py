@@ -56,6 +56,9 @@ def build_hip(force=False, verbose=False):
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
+        only = os.environ.get("BLA_BUILD_ONLY")   # experiments on one translation unit: "bla_gather.hip,bla_conv.hip" rebuilds just those (the others keep their objects)
+        if only and os.path.basename(s) not in only.split(",") and os.path.exists(o):
+            continue
         if force or _newer(o, [s] + hdrs):
             cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                    "-DBLA_BUILDING", "-I", INCLUDE, "-c", s, "-o", o] + os.environ.get("BLA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DBLA_WSK_DIAG

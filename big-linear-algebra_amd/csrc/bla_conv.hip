@@ -378,7 +378,6 @@ struct ConvArgs {
 	float* ep_out2 = nullptr;
 	int ep_bias_stride = 0;      // batched tiled forward only: bias set per image
 	bool ep_fused_tiled = false; // the tiled (padded-copy, half-slab) forward kernel applies the epilogue itself
-	bool a_tapmajor = false;     // A is already [M][(tap, channel)] (the unpadded tiled kernel's order): the caller took plan_forward's word for the path
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -692,80 +691,6 @@ static bla_status get_padded_tables(hipStream_t s, const ConvGeom& g, const int2
 	return BLA_OK;
 }
 
-// ---- tiled gather straight from the image (no padded copy), stride 1: gather modes 5 / 6 of bla_gemm.hip -------------------------------------
-// The contraction of the forward pass / data gradient runs TAP-MAJOR there, k = t * C + c: a 16-deep slab is 16 channels of one tap, so the tap's
-// shift (dy, dx) is one scalar per slab and the kernel can do by itself what the zero padding of the copy did (rows outside the image from a
-// zero word, the one element beyond a row's end patched in LDS).  The kernel matrix [M][(c, t)] is re-ordered to [M][(t, c)] by one small launch.
-__global__ void __launch_bounds__(kThreads) tapmajor_kernels_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int c_n, int kk) {
-	const int kdim = c_n * kk, total = rows * kdim;
-	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {   // e = (m, t, c): coalesced writes
-		const int m = e / kdim, r = e - m * kdim, t = r / c_n, c = r - t * c_n;
-		out[e] = a[(size_t)m * kdim + c * kk + t];
-	}
-}
-// the data gradient's kernel matrix, flipped and tap-major in one pass: out[c][t * F + f] = kern[f][c][k*k - 1 - t]  (flip_kernels_kernel, then tapmajor_kernels_kernel)
-__global__ void __launch_bounds__(kThreads) flip_tapmajor_kernels_kernel(const float* __restrict__ kern, float* __restrict__ out, int f_n, int c_n, int k) {
-	const int kk = k * k, kdim = f_n * kk, total = c_n * kdim;
-	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-		const int c = e / kdim, r = e - c * kdim, t = r / f_n, f = r - t * f_n;
-		out[e] = kern[((size_t)f * c_n + c) * kk + (kk - 1 - t)];
-	}
-}
-// slab s of the tap-major contraction (C / 16 slabs per tap): {c0 * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8}
-__global__ void __launch_bounds__(256) unpadded_slab_table_kernel(int2* tab, ConvGeom g) {
-	const int e = blockIdx.x * blockDim.x + threadIdx.x, per_tap = g.c / 16;
-	if (e >= g.k * g.k * per_tap) return;
-	const int t = e / per_tap, c0 = (e - t * per_tap) * 16, dy = t / g.k - g.pt, dx = t % g.k - g.pl;
-	tab[e] = make_int2(c0 * g.h * g.w + dy * g.w + dx, (dy & 255) | ((dx & 255) << 8));
-}
-// weight gradient: tap m = (c, p, q) -> {c * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8};  per 16 pixels of an image (one 16-deep slab of the
-// contraction) one int4: i | j << 16 of the first pixel of each of its four chunks
-__global__ void __launch_bounds__(256) unpadded_wgrad_tables_kernel(int2* taps, int* pix, ConvGeom g) {
-	const int e = blockIdx.x * blockDim.x + threadIdx.x, kk = g.k * g.k;
-	if (e < g.c * kk) { const int c = e / kk, t = e - c * kk, dy = t / g.k - g.pt, dx = t % g.k - g.pl; taps[e] = make_int2(c * g.h * g.w + dy * g.w + dx, (dy & 255) | ((dx & 255) << 8)); }
-	if (e < g.h * g.w / 4) { const int r = e * 4, i = r / g.w, j = r - i * g.w; pix[e] = i | (j << 16); }
-}
-struct UnpaddedTables { int device; ConvGeom g; int2* slabs; int2* taps; int2* pix; };
-static std::vector<UnpaddedTables> g_unpadded;
-
-static bla_status get_unpadded_tables(hipStream_t s, const ConvGeom& g, const int2** slabs, const int2** taps, const int2** pix) {
-	std::lock_guard<std::mutex> lk(g_table_mu);
-	const int dev = ctx().device;
-	for (const UnpaddedTables& e : g_unpadded) {
-		const ConvGeom& t = e.g;
-		if (e.device == dev && t.h == g.h && t.w == g.w && t.k == g.k && t.c == g.c && t.pt == g.pt && t.pl == g.pl) {
-			if (slabs) *slabs = e.slabs;
-			if (taps) *taps = e.taps;
-			if (pix) *pix = e.pix;
-			return BLA_OK;
-		}
-	}
-	bla_status st = table_build_allowed(s);
-	if (st) return st;
-	UnpaddedTables n = {dev, g, nullptr, nullptr, nullptr};
-	const int ns = g.k * g.k * ((g.c + 15) / 16), nt = g.c * g.k * g.k, np = g.h * g.w;
-	BLA_HIP(hipMalloc((void**)&n.slabs, (size_t)ns * sizeof(int2)));
-	BLA_HIP(hipMalloc((void**)&n.taps, (size_t)nt * sizeof(int2)));
-	BLA_HIP(hipMalloc((void**)&n.pix, ((size_t)np / 4 + 4) * sizeof(int)));   // (read as int4 per 16 pixels: 16-byte aligned by hipMalloc)
-	if (g.c % 16 == 0) hipLaunchKernelGGL(unpadded_slab_table_kernel, dim3((ns + 255) / 256), dim3(256), 0, ctx().stream, n.slabs, g);
-	const int cnt = nt > np ? nt : np;
-	hipLaunchKernelGGL(unpadded_wgrad_tables_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx().stream, n.taps, (int*)n.pix, g);
-	BLA_HIP(hipGetLastError());
-	BLA_HIP(hipStreamSynchronize(ctx().stream));
-	g_unpadded.push_back(n);
-	if (slabs) *slabs = n.slabs;
-	if (taps) *taps = n.taps;
-	if (pix) *pix = n.pix;
-	return BLA_OK;
-}
-// geometry the unpadded kernels take: stride 1, shifts of at most one column (k <= 3), rows of whole 16-byte chunks.  BLA_CONV_UNPADDED=0 keeps the padded copy.
-static bool unpadded_geometry(const ConvGeom& g) {
-	static const bool off = [] { const char* e = getenv("BLA_CONV_UNPADDED"); return e && e[0] == '0'; }();
-	// (rows of at least four 16-byte chunks: the kernels' counted wait needs every DMA instruction to keep a lane that is not a row end; the 8- and
-	// 4-pixel-wide maps stay on the padded copy, which is a few KB there)
-	return !off && g.s == 1 && g.k <= 3 && g.w % 4 == 0 && g.w >= 16 && g.ho == g.h && g.wo == g.w && g.pl <= 1 && g.k - 1 - g.pl <= 1 && g.h < 32768 && g.w < 32768;
-}
-
 // A batch large enough to fill the chip with 128x128 tiles goes to the LDS-tiled gather kernel (bla_gemm.hip: same pipeline as the
 // dense GEMM, the B slab fetched by 4-byte direct-to-LDS loads from computed addresses); small batches and odd shapes stay on the
 // 32x32 wave-split-K gather kernel above.
@@ -783,7 +708,24 @@ static bool use_tiled_gather(const ConvArgs& a, int batch, int mode) {
 
 // Which kernel a forward-shaped pass (forward, stride-1 data gradient) runs on, decided in ONE place: conv2d_forward asks it whether the tile store
 // will apply the epilogue, launch_implicit follows it.
-enum FwdPath { FWD_WSK = 0, FWD_TILED_CHECKED = 1, FWD_TILED_PADDED = 3, FWD_TILED_UNPADDED = 5 };
+enum FwdPath { FWD_WSK = 0, FWD_TILED_CHECKED = 1, FWD_TILED_PADDED = 3, FWD_TILED_WINDOW = 7 };
+// The image window in LDS (gather mode 7 of bla_gemm_kernel.h): 3x3, stride 1, SAME padding of one pixel, image rows of 16 or 32 pixels, whole 128-pixel
+// tiles inside one image, channels in groups of 16, one pass over K with a workgroup for about every CU.  BLA_CONV_WINDOW=0 keeps the padded copy.
+static bool window_geometry(const ConvArgs& a, int batch) {
+	static const bool off = [] { const char* e = getenv("BLA_CONV_WINDOW"); return e && e[0] == '0'; }();
+	const ConvGeom& g = a.g;
+	return !off && g.s == 1 && g.k == 3 && g.pt == 1 && g.pl == 1 && (g.w == 16 || g.w == 32) && g.ho == g.h && g.wo == g.w && (g.h * g.w) % 128 == 0 && g.c % 16 == 0 &&
+	       a.M % 128 == 0 && gather3_splits(a.M, a.N * batch, a.K) == 1 && (long)(a.M / 128) * ((long)a.N * batch / 128) >= 2L * (ctx().num_cus > 0 ? ctx().num_cus : 256);
+	// (two workgroups for every CU: with one, 256 -> 256 @16x16 x64 measured 193 us against 186 on the padded copy; with two, 128 -> 128 @32x32 x64 179 against 186)
+}
+// the kernel matrix [M][(c, t)] -> [M][(g, t, c16)], c = 16 g + c16: the contraction order of gather mode 7
+__global__ void __launch_bounds__(kThreads) window_order_kernels_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int c_n) {
+	const int kdim = c_n * 9, total = rows * kdim;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		const int m = e / kdim, r = e - m * kdim, g = r / 144, q = r - g * 144, t = q >> 4, c16 = q & 15;
+		out[e] = a[(size_t)m * kdim + (g * 16 + c16) * 9 + t];
+	}
+}
 struct FwdPlan { FwdPath path; bool fuses_epilogue; };
 static FwdPlan plan_forward(const ConvArgs& a, int batch) {
 	if (!use_tiled_gather(a, batch, 1)) return FwdPlan{FWD_WSK, batch == 1};   // (the 32x32 kernel applies one bias set where it stores: a single image)
@@ -791,7 +733,7 @@ static FwdPlan plan_forward(const ConvArgs& a, int batch) {
 	const bool fits32 = (size_t)batch * a.g.c * pg.plane_floats < ((size_t)1 << 29) && (long)batch * a.M * a.g.ho * a.g.wo < (1L << 29);
 	if (!fits32 || a.g.wo % 4 != 0) return FwdPlan{FWD_TILED_CHECKED, false};
 	const bool fuses = gather3_fuses_epilogue(a.M, a.N * batch, a.K);
-	if (unpadded_geometry(a.g) && a.g.c % 16 == 0 && gather_whole_tiles(5, a.M, a.N * batch)) return FwdPlan{FWD_TILED_UNPADDED, fuses};
+	if (window_geometry(a, batch)) return FwdPlan{FWD_TILED_WINDOW, true};
 	return FwdPlan{FWD_TILED_PADDED, fuses};
 }
 
@@ -826,26 +768,15 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 	const FwdPlan plan = MODE == CONV_FWD ? plan_forward(a, batch) : FwdPlan{FWD_WSK, false};
 	// ep_fused_tiled is conv2d_forward's word that the tile store applies the adds: it took that from the same plan (no second copy of the predicate)
 	BLA_REQUIRE(!a.ep_fused_tiled || (plan.fuses_epilogue && plan.path != FWD_WSK), BLA_ERR_INVALID, "internal: a fused epilogue was planned for a path that has none");
-	BLA_REQUIRE(!a.a_tapmajor || plan.path == FWD_TILED_UNPADDED, BLA_ERR_INVALID, "internal: tap-major kernels handed to a path that contracts channel-major");
-	if (MODE == CONV_FWD && plan.path == FWD_TILED_UNPADDED) {
-		// straight from the image: the kernel matrix goes tap-major into the workspace ([slabs][kernels]), then one gathered product
-		const int splits5 = gather3_splits(a.M, a.N * batch, a.K);
-		const size_t slab_bytes = splits5 > 1 ? ((size_t)splits5 * a.M * a.N * batch * sizeof(float) + 255) / 256 * 256 : 0;
+	if (MODE == CONV_FWD && plan.path == FWD_TILED_WINDOW) {
+		// straight from the image: the kernel matrix goes into the window kernel's contraction order in the workspace, then one product
 		void* ws;
-		bla_status st = ensure_workspace(slab_bytes + (a.a_tapmajor ? 0 : (size_t)a.M * a.K * sizeof(float)) + 64, &ws);
+		bla_status st = ensure_workspace((size_t)a.M * a.K * sizeof(float) + 64, &ws);
 		if (st) return st;
-		const float* a5 = a.A;
-		const int2* slabs;
-		st = get_unpadded_tables(s, a.g, &slabs, nullptr, nullptr);
-		if (st) return st;
-		if (!a.a_tapmajor) {
-			float* re = (float*)((char*)ws + slab_bytes);
-			hipLaunchKernelGGL(tapmajor_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, re, a.M, a.g.c, a.g.k * a.g.k);
-			BLA_HIP(hipGetLastError());
-			a5 = re;
-		}
+		hipLaunchKernelGGL(window_order_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, (float*)ws, a.M, a.g.c);
+		BLA_HIP(hipGetLastError());
 		const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
-		return gather_gemm(s, 5, batch, a.M, a.N * batch, a.K, a5, a.K, a.out, a.ldo, a.img, slabs, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
+		return gather_gemm(s, 7, batch, a.M, a.N * batch, a.K, (const float*)ws, a.K, a.out, a.ldo, a.img, nullptr, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
 		                   a.ep_fused_tiled ? &gep : nullptr);
 	}
 	if (MODE == CONV_FWD ? plan.path != FWD_WSK : use_tiled_gather(a, batch, 2)) {
@@ -875,13 +806,6 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		}
 		if (MODE == CONV_FWD)   // columns = (image, output pixel), contraction over the taps
 			return gather_gemm(s, 1, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, a.img, a.tab, ptab, a.g.h, a.g.w, a.N, (int)img_stride);
-		if (MODE == CONV_WGRAD && fits32 && a.g.wo % 4 == 0 && a.N % 4 == 0 && unpadded_geometry(a.g) && gather_whole_tiles(6, a.N, a.M)) {
-			// transposed product straight from the image: taps are the rows, both operands stream in 16-byte chunks, no padded copy
-			const int2 *taps, *pix;
-			st = get_unpadded_tables(s, a.g, nullptr, &taps, &pix);
-			if (st) return st;
-			return gather_gemm(s, 6, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, pix, taps, a.g.h, a.g.w, a.K, (int)img_stride);
-		}
 		if (MODE == CONV_WGRAD && fits32 && a.g.wo % 4 == 0 && a.N % 4 == 0) {
 			// transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const size_t slab_bytes = ((size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float) + 255) / 256 * 256;
@@ -1331,15 +1255,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
 		if (parity_dgrad_applies(batch, h, w, k, c_in, f_n, stride, gm)) return conv2d_backward_parity(s, d_del_y, d_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, gm);
 		int total = f_n * c_in * k * k;
-		bool tapmajor = false;
-		if (stride == 1) {   // will the stride-1 pass below run straight from del_y (tap-major contraction)?  Then the flipped kernels are written in that order at once
-			ConvArgs q;
-			q.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
-			q.A = d_scratch; q.lda = k * k * f_n; q.M = c_in; q.N = h * w; q.K = k * k * f_n;
-			tapmajor = plan_forward(q, batch).path == FWD_TILED_UNPADDED;
-		}
-		if (tapmajor) hipLaunchKernelGGL(flip_tapmajor_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
-		else hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
 		BLA_HIP(hipGetLastError());
 		// Stride s > 1 (the intended adjoint; the reference is undefined there): the same stride-1 convolution over del_y with s-1 zeros
 		// put between its pixels, [F][(Ho-1)s+1][(Wo-1)s+1] -- the U-Net's three down-convolutions (model/cifar_unet.c:1105,1111,1115).
@@ -1362,7 +1278,6 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
-		a.a_tapmajor = tapmajor;
 		st = launch_implicit<CONV_FWD>(s, a, batch, src_sz, x_sz, 0);
 		if (st) return st;
 	}

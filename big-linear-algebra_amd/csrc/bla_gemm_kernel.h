@@ -35,16 +35,14 @@ struct GemmArgs {
 	//   mode 4 (weight gradient, stride 1, padded copy), transposed: C'[tap][f] = sum_(image,pixel) P[tap][(image,pixel)] . del_y[f][(image,pixel)]:
 	//           both operands K-contiguous (the gathered one in 16-byte chunks of four pixels), B = del_y [image][N][HWo], the tile is
 	//           stored transposed (dkern [f][tap], or slab [split][f][tap])
-	//   mode 5 (forward / data gradient, stride 1, the image AS IT IS -- no padded copy): K runs tap-major, k = t * C + c (C % 16 == 0: a 16-deep slab is
-	//           16 channels of ONE tap), so the tap's shift (dy, dx) is a scalar per slab.  Four consecutive output pixels of a row are four consecutive
-	//           floats of the image row (i + dy) shifted by dx: the same 16-byte DMA, with the two things zero padding used to give done in the kernel --
-	//           a lane whose row i + dy falls outside the image fetches from a zero word, and a lane whose chunk hangs over the left / right end of its
-	//           row (|dx| <= 1: one element) does not DMA but loads its three in-row floats into registers and writes the chunk, zero included, into
-	//           the LDS image itself one phase later.  g_ktab[slab] = {c0 * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8}.
-	//   mode 6 (weight gradient, stride 1, unpadded), transposed like mode 4: the gathered operand is A [tap][(image, pixel)]; tap (c, p, q) is a lane
-	//           constant, the slab's four pixel chunks are scalars: g_ntab[tap] = {c * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8},
-	//           g_ktab = one int4 per 16 pixels of an image: i | j << 16 of the first pixel of its four chunks.  Same zero-row and row-end handling per lane.
-	//           Both modes: rows of at least four chunks (W >= 16), |dx| <= 1.
+	//   mode 7 (forward / data gradient, 3x3, stride 1, image rows of 16 or 32 pixels, straight from the image): "im2col into LDS".  A tile is 128
+	//           consecutive pixels = 128 / W whole rows of ONE image.  The contraction runs k = (g * 9 + t) * 16 + c: channel group g (16 channels),
+	//           tap t, channel c of the group -- so the 9 slabs of a group all read the SAME 16 channel planes, and what sits in LDS is not the
+	//           im2col slab [16][128] but the image window itself: per channel the 128 / W + 2 rows the tile's taps touch (rows outside the image
+	//           from a zero word), 16 planes per group, two groups (double buffer).  The window of group g + 1 is fetched by 16-byte DMAs (ALIGNED:
+	//           whole image rows) during the first slabs of group g -- nine slabs ahead of its use, one ninth of the im2col's bytes plus the halo
+	//           rows -- and an MFMA's B fragment is read at plane c, row r + p, column x + q - 1; a lane at a row's end gets its out-of-row tap as a
+	//           zero by a select.  No padded copy, no gather table, nothing per slab but one address add.  A [M][(g, t, c)] is re-ordered by the host.
 	const float* g_img; const float* g_zero;
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
@@ -87,6 +85,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   RC operand: image [BK][rows], read with ds_read_b32 of 32 consecutive floats -- no swizzle.
 // Needs K % BK == 0, 16-byte aligned rows and contiguous extents that are multiples of 4; rows /
 // columns past M / N are fetched from clamped addresses (their products are never stored).
+// mode 7: 16-byte chunk q of a channel group's image window ([16 planes][PL / GW rows][GW]) -> element offset in the image batch (channel group 0),
+// -1 when its image row does not exist (the chunk is then fetched from the zero words)
+template <int PL, int GW>
+__device__ __forceinline__ int window_chunk_offset(int q, int i0, int img_h, int img_hw, int img_base) {
+	const int plane = q / (PL / 4), r = q - plane * (PL / 4), wrow = r / (GW / 4), c4 = r - wrow * (GW / 4);
+	const int row = i0 - 1 + wrow;
+	return (unsigned)row < (unsigned)img_h ? img_base + plane * img_hw + row * GW + c4 * 4 : -1;
+}
+
 template <int ROWS, int BK>
 struct KcImage {  // ROWS x BK floats, K contiguous
 	static constexpr int CPR = BK / 4;                       // chunks per row: 4 (BK=16) or 8 (BK=32)
@@ -104,17 +111,21 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 // meet in LDS after the K loop (group order).  Two waves per SIMD on a tile that would otherwise give every SIMD one wave with one accumulator
 // block (64x64: a lone wave's waits and barrier skew leave the matrix pipe idle).
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false,
-          int WK = 1>
+          int WK = 1, int GW = 0>
 __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
-	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4 || GATHER == 6) && NBUF == 2 && !PERSIST && BM == 128 && (BN == 128 || (BN == 256 && (GATHER == 3 || GATHER == 5) && HS)) && BK == 16 && WM * WN == 4),
-	              "gather variants: A K-contiguous; modes 1-3, 5 gather B as a [16][128] image (modes 3, 5 on the half-slab pipeline: [16][256] too), modes 4, 6 gather A and take a K-contiguous B");
-	static_assert((GATHER != 5 && GATHER != 6) || HS, "the unpadded modes exist on the half-slab pipeline only");
-	constexpr bool G_FWD = GATHER == 3 || GATHER == 5, G_WG = GATHER == 4 || GATHER == 6;   // which operand is gathered on the 16-byte paths: B / A
+	static_assert(GATHER != 7 || (HS && (GW == 16 || GW == 32) && WM == 2 && WN == 2 && BN == 128), "mode 7: half-slab pipeline, image rows of 16 or 32 pixels");
+	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && (BN == 128 || (BN == 256 && GATHER == 3 && HS)) && BK == 16 && WM * WN == 4),
+	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image (mode 3 on the half-slab pipeline: [16][256] too), mode 4 gathers A and takes a K-contiguous B");
 	// mode 3: one wave-instruction of the B image (1 KiB = 256 floats) covers G3_RPI k-rows of BN / 4 sixteen-byte chunks each
 	constexpr int G3_CPR = BN / 4, G3_RPI = 64 / (G3_CPR < 64 ? G3_CPR : 64);
 	constexpr int NW = WM * WN * WK;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-	constexpr int A_SZ = BM * BK, B_SZ = BN * BK, KK = BK / 8, KKW = KK / WK;   // KKW: k-parts of a slab this wave multiplies
+	constexpr bool G7 = GATHER == 7;
+	constexpr int GWS = GW ? GW : 32;   // (a valid divisor in the instantiations that have no image width)
+	constexpr int A_SZ = BM * BK, B_SZ = G7 ? 0 : BN * BK, KK = BK / 8, KKW = KK / WK;   // KKW: k-parts of a slab this wave multiplies
+	// mode 7: the image window in LDS behind the two A slab buffers -- [2 groups][16 planes][W7_RH rows][GW] floats, 16 bytes of slack before and after
+	constexpr int W7_RH = G7 ? 128 / GWS + 2 : 1, W7_PL = W7_RH * GWS, W7_GRP = 16 * W7_PL, W7_NI = W7_GRP / 256, W7_PW = (W7_NI + 3) / 4;
+	static_assert(!G7 || W7_GRP % 256 == 0, "a group is a whole number of 1-KiB DMA instructions");
 	static_assert(WK == 1 || (KK % WK == 0 && NBUF == 2 && !PERSIST && GATHER == 0 && !HS && !(TM == 4 && TN == 4)), "waves along K: the plain two-buffer pipeline only");
 	typedef KcImage<BM, BK> AI;
 	typedef KcImage<BN, BK> BI;
@@ -136,12 +147,12 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		tm0 = (first_m + (pid % per_group) % gsz) * BM; tn0 = ((pid % per_group) / gsz) * BN;
 	};
 	int m0, n0;   // origin of the tile being COMPUTED (the persistent variant fetches one tile ahead)
-	// Weight gradient (modes 4, 6: few tiles, K cut over many workgroups): every tile of one K-split reads the same del_y columns, and the hardware
+	// Weight gradient (mode 4: few tiles, K cut over many workgroups): every tile of one K-split reads the same del_y columns, and the hardware
 	// deals consecutive workgroup ids round-robin to the 8 XCDs -- with (tile, split) = (blockIdx.x, blockIdx.z) the tiles of a split land on
 	// different XCDs and each L2 fetches that split's del_y for itself (349 MB of fills for 68 MB of operands at 128->128 @32x32 x64).  So XCD x takes
 	// the splits s = x (mod 8) and walks them tile by tile: the tiles of a split are neighbours in ONE XCD's dispatch order and share its L2.
 	int vblock = blockIdx.x, zsplit = blockIdx.z;
-	if (G_WG && (gridDim.z & 7) == 0) {
+	if (GATHER == 4 && (gridDim.z & 7) == 0) {
 		const int lin = blockIdx.z * gridDim.x + blockIdx.x, i = lin >> 3;
 		zsplit = (i / (int)gridDim.x) * 8 + (lin & 7); vblock = i % (int)gridDim.x;
 	}
@@ -173,7 +184,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 				ga[i] = p.A + (size_t)(k_begin + kr) * p.lda + min(tm0 + c, p.M - 4);
 			}
 		}
-		if ((GATHER >= 1 && GATHER <= 3) || GATHER == 5) {
+		if ((GATHER >= 1 && GATHER <= 3) || G7) {
 			// nothing per tile for B: the gather addresses are rebuilt per slab from the lane / scalar table entries below
 		} else if (BKC) {
 #pragma unroll
@@ -197,16 +208,13 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	bool g_lval[2] = {false, false};
 	int g_k = k_begin;            // k of the next slab to fetch
 	int g_img = 0, g_r = 0;       // mode 2: image and pixel of g_k
-	int g4_tap[A_NI], g4_chunk[A_NI];   // modes 4, 6: (padded) offset of this lane's tap row, and its (swizzled) pixel chunk, per A instruction
-	int g6_dy[A_NI], g6_dx[A_NI];       // mode 6: the tap's shift
-	if (G_WG) {
+	int g4_tap[A_NI], g4_chunk[A_NI];   // mode 4: padded offset of this lane's tap row, and its (swizzled) pixel chunk, per A instruction
+	if (GATHER == 4) {
 #pragma unroll
 		for (int i = 0; i < A_NI; i++) {
 			int inst = wave * A_NI + i;
 			int r = inst * AI::RPI + lane / AI::CPR, pos = lane % AI::CPR;
-			const int2 te = p.g_ntab[min(m0 + r, p.M - 1)];
-			g4_tap[i] = te.x;
-			g6_dy[i] = (int)(signed char)(te.y & 0xff); g6_dx[i] = (int)(signed char)((te.y >> 8) & 0xff);
+			g4_tap[i] = p.g_ntab[min(m0 + r, p.M - 1)].x;
 			g4_chunk[i] = AI::swz(r, pos) * 4;
 		}
 		g_img = k_begin / p.g_HWo; g_r = k_begin - g_img * p.g_HWo;
@@ -219,17 +227,20 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		int b = n / p.g_HWo, r = n - b * p.g_HWo;
 		g3_base = p.g_ntab[r].x + b * p.g_img_stride;
 	}
-	// mode 5: this lane's four output pixels (image b, row u_i, columns j0 .. j0 + 3) as an element offset into the image batch (plus one channel for
-	// the second k-row of a 128-column instruction), and whether its chunk starts / ends an image row
-	int u_i = 0;
-	bool u_left = false, u_right = false;
-	if (GATHER == 5) {
-		const int n = n0 + (lane % G3_CPR) * 4;           // whole tiles only
-		const int b = n / p.g_HWo, r = n - b * p.g_HWo;
-		u_i = r / p.g_W;
-		const int j0 = r - u_i * p.g_W;
-		u_left = j0 == 0; u_right = j0 + 4 == p.g_W;
-		g3_base = b * p.g_img_stride + r + (lane / G3_CPR) * p.g_HWo;
+	// mode 7: this wave's window DMA instructions jw = wave + 4 i of a group -- chunk q = 64 jw + lane of the group's 16 planes: plane q / (PL/4), window
+	// row, 16-byte column -- as an element offset into the image batch (group 0; a group adds 16 planes) and whether that image row exists; the
+	// fragment reads' lane offset; whether the lane's pixel column is a row's first / last
+	// (the chunk's offset is worked out when its instruction is issued -- three times per nine slabs: kept in three registers and picked by the run-time
+	// tap, hipcc turns the pick into a scratch array, and with it the whole argument block: 720 bytes of scratch per lane, seen in the ISA)
+	int w7_i0 = 0, w7_base = 0;
+	unsigned w7_lane = 0;
+	bool w7_left = false, w7_right = false;
+	if (G7) {
+		const int b = n0 / p.g_HWo, i0 = (n0 - b * p.g_HWo) / GWS;    // the tile: rows i0 .. i0 + 128 / GW - 1 of image b
+		w7_i0 = i0; w7_base = b * p.g_img_stride;
+		w7_lane = (unsigned)((4 * h * W7_PL + wn0 + l31) * 4);
+		const int col = (wn0 + l31) % GWS;
+		w7_left = col == 0; w7_right = col == GWS - 1;
 	}
 	if (GATHER == 1 || GATHER == 2) {
 #pragma unroll
@@ -261,7 +272,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	// where the global form drops to 128, but on power-of-two pitches up to 16 KiB the global form is 1-4 % ahead (4096^3: 142.7 vs 141.0).
 	// Compile-time: choosing between the two forms at run time inside the loop costs 4 %.
 	constexpr bool BUF_OK = GATHER == 0 && !PERSIST;   // (the persistent variant re-bases its pointers per tile)
-	constexpr bool A_BUF = (BUF_OK && (AKC || !RCG)) || G_FWD, B_BUF = (BUF_OK && (BKC || !RCG)) || G_WG;   // 16-byte conv modes: their dense operand too
+	constexpr bool A_BUF = (BUF_OK && (AKC || !RCG)) || GATHER == 3 || G7, B_BUF = (BUF_OK && (BKC || !RCG)) || GATHER == 4;   // padded-copy conv modes: their dense operand too
 #if defined(__HIP_DEVICE_COMPILE__)
 	// raw descriptors, no bounds (rows / columns past the matrix are fetched from clamped offsets); lane offsets in bytes
 	__amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7fffffff, 0x00020000);
@@ -442,39 +453,21 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	// the half-slab interleaved pipeline: always for 4x4 blocks per wave (256x256, 128x512), on request (HS) for 2x2 (128x128)
 	// (the padded-copy convolution modes 3 / 4 run on it too: their gather is one more address per DMA instruction, dealt out between MFMAs like the rest)
 	constexpr bool HALFSLAB = ((TM == 4 && TN == 4) || (HS && TM >= 2 && TM <= 4 && TN >= 2 && TN <= 4)) && (KK == 2 || KK == 4) &&
-	                          (GATHER == 0 || ((G_FWD || G_WG) && HS)) && !PERSIST && NBUF == 2;
-	constexpr int NDMA = A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32)
+	                          (GATHER == 0 || ((GATHER == 3 || GATHER == 4 || G7) && HS)) && !PERSIST && NBUF == 2;
+	constexpr int NDMA = G7 ? A_NI + 1 : A_NI + B_NI;   // DMA instructions per wave per slab (8 at BK = 16, 16 at BK = 32; mode 7: A and at most one window instruction)
 	size_t g_adv_a = 0, g_adv_b = 0;   // global-form operands of the half-slab pipeline: scalar advance added to the per-lane pointers
+	int w7_tap = 0, w7_g = 0;                                    // mode 7: tap and channel group of the slab being computed
+	const int w7_groups = G7 ? (p.g_img_stride / p.g_HWo) / 16 : 0, w7_gstep = 16 * p.g_HWo;
+	// (plain values, not members of p: a select between p.g_img + x and p.g_zero hipcc rewrites as a load through a selected ADDRESS of the member,
+	// which puts the whole argument block into scratch -- 720 bytes per lane, seen in the ISA)
+	const float* const w7_img = p.g_img;
+	const float* const w7_zero = p.g_zero;
 #if defined(__HIP_DEVICE_COMPILE__)
 	// Gather tables of the half-slab pipeline: the entries a slab's DMA instructions need are wave-uniform (tap rows of mode 3, the four
 	// pixel chunks of mode 4), so they are SCALAR loads, issued when the cursor moves -- a whole slab before the DMA that uses them.  (A per-lane
 	// table load in front of each DMA waits on vmcnt, i.e. for every LDS-DMA issued before it: 256->256 @16x16 ran 11 % slower that way.)
 	int hs_tap[B_NI][2], hs_pix[4] = {0, 0, 0, 0};
-	// modes 5 / 6 (no padded copy): the scalar entry of the slab being fetched, and what is left to do for the slab fetched before it -- a lane whose
-	// chunk hangs over the end of its image row loaded its three in-row floats into registers instead of issuing its DMA (u_fix), and writes the
-	// chunk with its zero into the LDS image in the next phase 0 (apply_fix), before the barrier that publishes that slab.
-	constexpr int NFIX = GATHER == 5 ? B_NI : GATHER == 6 ? A_NI : 1;
-	typedef float v3f __attribute__((ext_vector_type(3)));
-	v3f u_fix[NFIX];
-	int u_kind[NFIX];                    // per lane and instruction: 0 = the DMA fetched the chunk, 1 = {0, f0, f1, f2} (left end), 2 = {f0, f1, f2, 0} (right end)
-#pragma unroll
-	for (int i = 0; i < NFIX; i++) { u_kind[i] = 0; u_fix[i] = v3f{0.f, 0.f, 0.f}; }
-	// Modes 5 / 6 load their ONE table entry per slab with an asm instruction: a load hipcc can see it follows -- when it can prove the address
-	// uniform -- with s_waitcnt vmcnt(0) + v_readfirstlane on the spot, a wait for every LDS-DMA in flight; and the order and number of this loop's
-	// vector-memory instructions must be exactly what apply_fix's counted wait assumes (three-float loads, then NDMA DMAs, then this one load).
-	typedef int v2i __attribute__((ext_vector_type(2)));
-	typedef int v4i __attribute__((ext_vector_type(4)));
-	v2i u_ent = v2i{0, 0};     // mode 5: {c0 * HW + dy * W + dx, (dy & 255) | (dx & 255) << 8} of the slab at the fetch cursor
-	v4i u_pix = v4i{0, 0, 0, 0};   // mode 6: i | j << 16 of the first pixel of the slab's four chunks
 	auto hs_prefetch = [&]() {
-		if (GATHER == 5) {
-			const int2* e = p.g_ktab + (g_k >> 4);
-			asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(u_ent) : "v"(e) : "memory");
-		}
-		if (GATHER == 6) {
-			const int4* e = reinterpret_cast<const int4*>(p.g_ktab) + (g_r >> 4);      // g_ktab: one int4 per 16 pixels of an image
-			asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(u_pix) : "v"(e) : "memory");
-		}
 		if (GATHER == 3) {
 #pragma unroll
 			for (int i = 0; i < B_NI; i++) {
@@ -488,75 +481,32 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 			for (int c = 0; c < 4; c++) hs_pix[c] = p.g_ktab[r + 4 * c].x;
 		}
 	};
-	if (HALFSLAB && (G_FWD || G_WG)) hs_prefetch();
-	if (GATHER == 5 || GATHER == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the asm table load: the first fetch below reads its entry at once)
-	// One gathered 16-byte chunk without a padded copy.  unpadded_chunk(slot): where the chunk's first float is (one float before / beyond its row for a
-	// row-end chunk), whether its image row exists, and its kind (u_kind).  A row-end chunk of an existing row is NOT fetched by DMA (its lane is masked
-	// out of the instruction): its lane loads the three in-row floats into registers -- fix_load, issued for all of a slab's instructions BEFORE the
-	// slab's DMAs, so that apply_fix can wait for exactly these loads with a counted s_waitcnt -- and writes the chunk, zero included, into LDS itself.
-	struct Chunk { const float* src; bool row_ok; int kind; };
-	auto unpadded_chunk = [&](int slot) -> Chunk {
-		if (GATHER == 5) {   // channel c0 + k-row of the slab's one tap; the tap's shift is the scalar entry
-			const int idx = wave * B_NI + slot;
-			const int dy = (int)(signed char)(u_ent.y & 0xff), dx = (int)(signed char)((u_ent.y >> 8) & 0xff);
-			const bool row_ok = (unsigned)(u_i + dy) < (unsigned)p.g_H;
-			const int kind = !row_ok ? 0 : (dx < 0 && u_left) ? 1 : (dx > 0 && u_right) ? 2 : 0;
-			return Chunk{p.g_img + (g3_base + (u_ent.x + idx * G3_RPI * p.g_HWo)), row_ok, kind};
-		}
-		// mode 6: four pixels (row pi, columns pj ..) of this lane's tap row, shifted by the tap's (dy, dx)
-		const int c = g4_chunk[slot] >> 2;
-		const int py = c == 0 ? u_pix.x : c == 1 ? u_pix.y : c == 2 ? u_pix.z : u_pix.w;
-		const int pi = py & 0xffff, pj = py >> 16;
-		const bool row_ok = (unsigned)(pi + g6_dy[slot]) < (unsigned)p.g_H;
-		const int kind = !row_ok ? 0 : (g6_dx[slot] < 0 && pj == 0) ? 1 : (g6_dx[slot] > 0 && pj + 4 == p.g_W) ? 2 : 0;
-		return Chunk{p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[slot] + g_r + 4 * c), row_ok, kind};
-	};
-	auto fix_load = [&](int slot) {   // every lane loads (a lane without a row end: from the zero words, never used) -- no branch around an asm result
-		const Chunk ch = unpadded_chunk(slot);
-		const float* q = ch.kind != 0 ? ch.src + (ch.kind == 1 ? 1 : 0) : p.g_zero;
-		u_kind[slot] = ch.kind;
-		asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(u_fix[slot]) : "v"(q) : "memory");
-	};
-	auto fetch_unpadded = [&](float* lds_dst, int slot) {
-		const Chunk ch = unpadded_chunk(slot);
-		const float* src = ch.row_ok ? ch.src : p.g_zero;                     // a row outside the image: sixteen bytes of zeros
-		// (the host sends only rows of >= 4 chunks here: some lane of every instruction has kind 0, so the instruction is never skipped as a whole --
-		// apply_fix's counted wait relies on every DMA instruction being issued)
-		if (ch.kind == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
-	};
-	auto apply_fix = [&](int buf) {   // the row-end chunks of the slab in LDS buffer `buf` (fetched by the last fetch_slab / last phase); the caller has waited for the fix loads
-		if (GATHER != 5 && GATHER != 6) return;
-		typedef float v4f __attribute__((ext_vector_type(4)));
-		typedef __attribute__((address_space(3))) float* lds_fp;
-		// (the LDS write is asm: in front of an LDS access it can see behind an LDS-DMA hipcc puts s_waitcnt vmcnt(0), which would make the caller's
-		// counted wait pointless)
-		const unsigned base = (unsigned)(size_t)(lds_fp)lds + (unsigned)((buf * (A_SZ + B_SZ) + (GATHER == 5 ? A_SZ : 0) + wave * NFIX * 256 + lane * 4) * 4);
-#pragma unroll
-		for (int i = 0; i < NFIX; i++) {
-			if (u_kind[i] != 0) {
-				const v4f v = u_kind[i] == 1 ? v4f{0.f, u_fix[i].x, u_fix[i].y, u_fix[i].z} : v4f{u_fix[i].x, u_fix[i].y, u_fix[i].z, 0.f};
-				asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(base), "v"(v), "n"(i * 1024) : "memory");
-			}
-		}
-	};
+	if (HALFSLAB && (GATHER == 3 || GATHER == 4)) hs_prefetch();
+
 	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab; the offsets / gather cursors advance in dma_advance()
 		float* base = lds + buf * (A_SZ + B_SZ);
 		if (d < A_NI) {
 			const int i = d;
-			if (GATHER == 6) {   // gathered operand, straight from the image
-				fetch_unpadded(base + (wave * A_NI + i) * 256, i);
-			} else if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy)
+			if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy)
 				const int c = g4_chunk[i] >> 2;     // which of the slab's four pixel chunks this lane fetches: its offset was loaded a slab ahead (hs_pix)
 				const int pix = c == 0 ? hs_pix[0] : c == 1 ? hs_pix[1] : c == 2 ? hs_pix[2] : hs_pix[3];
 				const float* src = p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[i] + pix);
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 			} else if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + g_adv_a), (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+		} else if (G7) {
+			// the one window slot of a slab: instruction `w7_tap` of the NEXT group's window, in the first W7_PW slabs of a group (its buffer held the
+			// group before this one, which nobody reads any more) -- nine slabs ahead of its first use
+			if (w7_tap < W7_PW && wave + 4 * w7_tap < W7_NI && w7_g + 1 < w7_groups) {
+				const int i = w7_tap;
+				const int off = window_chunk_offset<W7_PL, GWS>((wave + 4 * i) * 64 + lane, w7_i0, p.g_H, p.g_HWo, w7_base);
+				const float* src = off >= 0 ? w7_img + (off + (w7_g + 1) * w7_gstep) : w7_zero;
+				float* dst = lds + 2 * A_SZ + 4 + ((w7_g + 1) & 1) * W7_GRP + (wave + 4 * i) * 256;
+				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+			}
 		} else {
 			const int i = d - A_NI;
-			if (GATHER == 5) {   // gathered operand, straight from the image
-				fetch_unpadded(base + A_SZ + (wave * B_NI + i) * 256, i);
-			} else if (GATHER == 3) {   // gathered operand: four consecutive output pixels = four consecutive floats of the padded copy, tap from the scalar table
+			if (GATHER == 3) {   // gathered operand: four consecutive output pixels = four consecutive floats of the padded copy, tap from the scalar table
 				const int idx = wave * B_NI + i;   // the instruction covers k-rows 2 idx (lanes 0-31) and 2 idx + 1 (BN = 256: the one row idx): their tap offsets were loaded a slab ahead (hs_tap)
 				const float* src = p.g_img + (g3_base + ((G3_RPI == 2 && (lane >> 5)) ? hs_tap[i][1] : hs_tap[i][0]));
 				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + A_SZ + idx * 256), 16, 0, 0);
@@ -566,8 +516,9 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	};
 	auto dma_advance = [&](bool really) {   // uniform select, no branch: past the last slab the cursor stays on it (harmless re-fetch)
 		const int sa = really ? (int)(a_step * 4) : 0, sb = really ? (int)(b_step * 4) : 0;
-		if (G_FWD) { soff_a += sa; g_k += really ? BK : 0; hs_prefetch(); return; }
-		if (G_WG) {   // B = del_y [image][N][HWo]: the pixel cursor wraps into the next image (HWo % 16 == 0: a slab never straddles two)
+		if (GATHER == 3) { soff_a += sa; g_k += really ? BK : 0; hs_prefetch(); return; }
+		if (G7) { soff_a += sa; return; }
+		if (GATHER == 4) {   // B = del_y [image][N][HWo]: the pixel cursor wraps into the next image (HWo % 16 == 0: a slab never straddles two)
 			const int r1 = g_r + (really ? BK : 0);
 			const bool wrap = r1 >= p.g_HWo;
 			soff_b += (really ? BK * 4 : 0) + (wrap ? (p.N - 1) * p.g_HWo * 4 : 0);
@@ -579,11 +530,8 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		if (B_BUF) soff_b += sb; else g_adv_b += really ? b_step : 0;
 	};
 #else
-	constexpr int NFIX = 1;
 	auto dma_one = [&](int, int) {};
 	auto dma_advance = [&](bool) {};
-	auto apply_fix = [&](int) {};
-	auto fix_load = [&](int) {};
 #endif
 	auto step = [&](int kt, bool do_dma, float (&pa)[KKW][TM][4], float (&pb)[KKW][TN][4], float (&qa)[KKW][TM][4], float (&qb)[KKW][TN][4]) {
 		// sched_barrier(0) pins the order: hipcc otherwise floats the MFMAs (which touch no memory) across the
@@ -602,7 +550,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	};
 
 	auto store_tile = [&]() {
-		if (G_WG) {   // transposed: tile element (row = tap, col = f) -> out[f][tap]; a lane's registers q&3 are 4 consecutive taps
+		if (GATHER == 4) {   // transposed: tile element (row = tap, col = f) -> out[f][tap]; a lane's registers q&3 are 4 consecutive taps
 			float* dst = p.splits > 1 ? p.slab + (size_t)zsplit * p.M * p.N : p.C;
 			const int ld = p.splits > 1 ? p.M : p.ldc;
 #pragma unroll
@@ -621,7 +569,27 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 			}
 			return;
 		}
-		if constexpr (G_FWD && HALFSLAB) {   // whole tiles; a lane owns TN consecutive columns (the row-contiguous operand's interleaved blocks)
+		if constexpr (G7) {   // whole tiles inside one image; block `in` owns the 32 consecutive pixels wn0 + 32 in + l31
+			const int b = n0 / p.g_HWo;
+			const size_t img_off = (size_t)b * p.M * p.g_HWo + (n0 - b * p.g_HWo) + wn0 + l31;
+			const float* bias = p.g_bias ? p.g_bias + (size_t)b * p.g_bias_stride : nullptr;
+#pragma unroll
+			for (int im = 0; im < TM; im++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int row = m0 + wm0 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+					const size_t o = img_off + (size_t)row * p.g_HWo;
+					const float bv = bias ? bias[row] : 0.f;
+#pragma unroll
+					for (int in = 0; in < TN; in++) {
+						const float v = acc[im][in][r] + bv;
+						p.C[o + in * 32] = v;
+						if (p.g_out2) p.g_out2[o + in * 32] = v + p.g_add[o + in * 32];
+					}
+				}
+			return;
+		}
+		if constexpr (GATHER == 3 && HALFSLAB) {   // whole tiles; a lane owns TN consecutive columns (the row-contiguous operand's interleaved blocks)
 			const int col = n0 + wn0 + TN * l31;              // TN consecutive pixels of one image (HWo % 4 == 0)
 			const int b = col / p.g_HWo, rr = col - b * p.g_HWo;
 			const size_t img_off = (size_t)b * p.M * p.g_HWo + rr;
@@ -761,12 +729,25 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 			vra ra[4]; vrb rb[4]; // row-contiguous: [k-offset j], elements = block
 			float sa[4][TM], sb[4][TN];   // row-contiguous with three blocks (192-wide tiles): 12-byte reads would be unaligned, so the blocks keep
 			                              // 32 consecutive rows each and a lane's three elements come as three dword reads
+			                              // (mode 7 uses sb too: element [j][block] is one dword of the image window)
 		};
 		Frag P, Q;
-		constexpr int UA = AKC ? TM : 4, UB = BKC ? TN : 4, NU = UA + UB;   // fragment-read units per k-part
+		// Whole-slab form (FS) for the forward / data-gradient convolution kernels (64 x 64 per wave: 16 MFMAs per k-part): a wave that stops at every
+		// k-part boundary for its fragments (land) AND at every slab for the barrier pays that fixed cost per 16 MFMAs -- a quarter of what the 256 x 256
+		// kernel's 64-MFMA phases pay it for.  With 64 accumulator registers there is room for TWO whole-slab fragment sets: slab t + 1's fragments are
+		// all read under slab t's 32 MFMAs, and a slab has ONE stop (land + vmcnt(0) + barrier, together) instead of three.
+		constexpr bool FS = (GATHER == 3 || G7) && TM == 2 && TN == 2 && KK == 2;
+		Frag F0[KK], F1[KK];
+		constexpr int UA = AKC ? TM : 4, UB = G7 ? 4 * TN : BKC ? TN : 4, NU = UA + UB;   // fragment-read units per k-part
+		// mode 7: byte address of (plane 0 of the group, tap) of the slab whose fragments are being read, plus this lane's part; [0] = slab t, [1] = slab t + 1
+		unsigned w7_ad[2] = {0, 0}, w7_cur = 0;   // w7_cur: the A buffer offset of slab t (read_unit is told a slab by its A buffer)
+		auto w7_addr = [&](int g, int tap) -> unsigned {   // tap (p, q): window row r + p, column x + q - 1
+			const int pq = tap / 3;
+			return lds0 + (unsigned)((2 * A_SZ + 4 + (g & 1) * W7_GRP + pq * GWS + (tap - 3 * pq) - 1) * 4) + w7_lane;
+		};
 		constexpr int NM = 4 * TM * TN;                                       // MFMAs per k-part
 		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.ka[im][j] : TM == 3 ? f.sa[j][im] : f.ra[j][im]; };
-		auto opb = [&](const Frag& f, int in, int j) -> float { return BKC ? f.kb[in][j] : TN == 3 ? f.sb[j][in] : f.rb[j][in]; };
+		auto opb = [&](const Frag& f, int in, int j) -> float { return G7 ? f.sb[j][in] : BKC ? f.kb[in][j] : TN == 3 ? f.sb[j][in] : f.rb[j][in]; };
 		auto mf1 = [&](const Frag& f, int idx) {   // idx-th MFMA of a k-part: j-major, then im, in
 			const int j = idx / (TM * TN), im = (idx % (TM * TN)) / TN, in = idx % TN;
 			acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(f, im, j), opb(f, in, j), acc[im][in], 0, 0, 0);
@@ -781,6 +762,12 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 					for (int b = 0; b < 3; b++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sa[x][b]) : "v"(ad), "n"((x * BM + b * 32) * 4));
 				} else if constexpr (TM == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
 				else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.ra[x]) : "v"(ad), "n"(x * BM * 4));
+			} else if constexpr (G7) {
+				// unit x = (j, block): channel kk * 8 + 4 h + j of the group (the 4 h planes are in the lane's address), pixels block * 32 + l31 of the wave's 64;
+				// `buf` is not a slab buffer here but which of the two slabs in flight (0: t, BUF_BYTES: t + 1)
+				const int x = u - UA, j = x / TN, b = x % TN;
+				const unsigned ad = buf == w7_cur ? w7_ad[0] : w7_ad[1];
+				asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sb[j][b]) : "v"(ad), "n"(((kk * 8 + j) * W7_PL + b * 32) * 4));
 			} else {
 				const int x = u - UA;
 				const unsigned ad = buf + b_ad[kk];
@@ -802,9 +789,20 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 			}
 #pragma unroll
 			for (int x = 0; x < UB; x++) {
-				if constexpr (BKC) asm volatile("" : "+v"(f.kb[x]));
+				if constexpr (G7) asm volatile("" : "+v"(f.sb[x / TN][x % TN]));
+				else if constexpr (BKC) asm volatile("" : "+v"(f.kb[x]));
 				else if constexpr (TN == 3) { asm volatile("" : "+v"(f.sb[x][0])); asm volatile("" : "+v"(f.sb[x][1])); asm volatile("" : "+v"(f.sb[x][2])); }
 				else asm volatile("" : "+v"(f.rb[x]));
+			}
+		};
+		auto w7_mask = [&](Frag& f) {   // mode 7: a lane on a row's first / last column gets its out-of-row tap (dx = -1 / +1) as a zero
+			if constexpr (G7) {
+				const int dx = w7_tap % 3 - 1;
+				const bool m = (dx < 0 && w7_left) || (dx > 0 && w7_right);
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+#pragma unroll
+					for (int b = 0; b < TN; b++) f.sb[j][b] = m ? 0.f : f.sb[j][b];
 			}
 		};
 		// slab t in buffer t&1.  One uniform body for every slab: past the end the fetch cursor stays on the last slab (re-fetched
@@ -812,44 +810,39 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		// code, no branch in the loop, and the 256 accumulators never leave their registers.
 		int fetched = 0;                       // slabs the cursor has been advanced past
 		auto fetch_slab = [&](int buf) {       // prologue form (clumped)
-			if constexpr (GATHER == 5 || GATHER == 6) {
 #pragma unroll
-				for (int i = 0; i < NFIX; i++) fix_load(i);
-			}
-#pragma unroll
-			for (int d = 0; d < NDMA; d++) dma_one(buf, d);
+			for (int d = 0; d < (G7 ? A_NI : NDMA); d++) dma_one(buf, d);
 			const bool adv = fetched + 1 < nkt;
 			dma_advance(adv); fetched += adv ? 1 : 0;
 		};
 		auto slab = [&](int t) {
 			const unsigned cur = (t & 1) * BUF_BYTES, nxt = ((t + 1) & 1) * BUF_BYTES;
+			if constexpr (G7) {   // where slab t and slab t + 1 read the window
+				const int tap1 = w7_tap == 8 ? 0 : w7_tap + 1, g1 = w7_tap == 8 ? w7_g + 1 : w7_g;
+				w7_cur = cur; w7_ad[0] = w7_addr(w7_g, w7_tap); w7_ad[1] = w7_addr(g1, tap1);
+			}
 			// phases 0 .. KK-2: k-part q from one set while k-part q+1 of this slab is read into the other, the read units spread evenly
 #pragma unroll
 			for (int q = 0; q + 1 < KK; q++) {
 				Frag& use = (q & 1) ? Q : P;
 				Frag& fill = (q & 1) ? P : Q;
 				land(use);
+				w7_mask(use);
+				// dense: the read units spread evenly over the phase.  Convolution modes (16 MFMAs per phase): one unit per MFMA from the start and the
+				// rest of the MFMAs behind them -- spread evenly, the last unit is issued some 100 cycles before land() waits for it, less than an LDS round trip
+				constexpr int FRONT = (GATHER != 0 && NU <= NM) ? 1 : 0;
 #pragma unroll
 				for (int u = 0; u < NU; u++) {
 					read_unit(cur, q + 1, u, fill);
 					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-					for (int m = u * NM / NU; m < (u + 1) * NM / NU; m++) mf1(use, m);
+					for (int m = FRONT ? u : u * NM / NU; m < (FRONT ? (u + 1 < NU ? u + 1 : NM) : (u + 1) * NM / NU); m++) mf1(use, m);
 					__builtin_amdgcn_sched_barrier(0);
-					if ((GATHER == 5 || GATHER == 6) && q == 0 && u == NU / 2) {
-						// the row-end chunks of slab t + 1, half a phase before the barrier that publishes the slab (land(Q) below waits for these LDS writes like
-						// for the reads).  Their register loads are OLDER than that slab's NDMA DMA instructions and the one table load behind them, and vector
-						// loads return in order: vmcnt(NDMA + 1) waits for exactly them, not for the DMAs issued half a slab ago.
-						constexpr int YOUNGER = (GATHER == 5 || GATHER == 6) ? NDMA + 1 : 0;
-						static_assert(YOUNGER <= 15, "counted wait");
-						asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-						apply_fix((t + 1) & 1);
-						__builtin_amdgcn_sched_barrier(0);
-					}
 				}
 			}
 			// last phase (k-part KK-1 from Q): slab t+1 has landed for everyone, and everyone is done reading slab t
 			land(Q);
+			w7_mask(Q);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 			// The gather-table entries for the DMAs below were loaded a slab ago and have landed with everything else (vmcnt(0) above) -- but hipcc does not
@@ -876,11 +869,6 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 				for (int m = 0; m < PER; m++) mf1(Q, PER * u + m);
 				__builtin_amdgcn_sched_barrier(0);
 			}
-			if constexpr (GATHER == 5 || GATHER == 6) {   // the row-end loads of slab t+2 go first: apply_fix waits for them by count (they are older than the DMAs)
-#pragma unroll
-				for (int i = 0; i < NFIX; i++) fix_load(i);
-				__builtin_amdgcn_sched_barrier(0);
-			}
 #pragma unroll
 			for (int d = 0; d < NDMA; d++) {  // slab t+2 -> this slab's buffer
 				dma_one(t & 1, d);
@@ -893,20 +881,83 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 #pragma unroll
 			for (int m = PER * (NU + NDMA); m < NM; m++) mf1(Q, m);
 			__builtin_amdgcn_sched_barrier(0);
+			if constexpr (G7) { const bool wrap = w7_tap == 8; w7_g += wrap ? 1 : 0; w7_tap = wrap ? 0 : w7_tap + 1; }   // on to slab t + 1
+		};
+		auto mf_fs = [&](Frag (&f)[KK], int idx) {   // idx-th MFMA of a slab: k-part major
+			mf1(f[idx / NM], idx % NM);
+		};
+		auto slab_fs = [&](int t, Frag (&use)[KK], Frag (&fill)[KK]) {
+			const unsigned nxt = ((t + 1) & 1) * BUF_BYTES;
+			if constexpr (G7) {
+				const int tap1 = w7_tap == 8 ? 0 : w7_tap + 1, g1 = w7_tap == 8 ? w7_g + 1 : w7_g;
+				w7_cur = (t & 1) * BUF_BYTES; w7_ad[0] = w7_addr(w7_g, w7_tap); w7_ad[1] = w7_addr(g1, tap1);
+			}
+			// the one stop of the slab: this slab's fragments are in registers, slab t + 1 has landed for every wave, nobody needs slab t's LDS any more
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+			for (int kk = 0; kk < KK; kk++) { land(use[kk]); w7_mask(use[kk]); }
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+#if defined(__HIP_DEVICE_COMPILE__)
+			if constexpr (GATHER == 3) {   // (the table entries' wait, where it is free: see slab())
+#pragma unroll
+				for (int i = 0; i < B_NI; i++) { asm volatile("" : "+v"(hs_tap[i][0])); if (G3_RPI == 2) asm volatile("" : "+v"(hs_tap[i][1])); }
+			}
+#endif
+			static_assert(!FS || KK * NU + NDMA <= KK * NM, "one memory instruction per MFMA");
+			int idx = 0;
+#pragma unroll
+			for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+				for (int u = 0; u < NU; u++) {   // slab t + 1 -> the other set (every LDS read before the first DMA)
+					read_unit(nxt, kk, u, fill[kk]);
+					__builtin_amdgcn_sched_barrier(0);
+					mf_fs(use, idx++);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+#pragma unroll
+			for (int d = 0; d < NDMA; d++) {     // slab t + 2 -> this slab's buffer
+				dma_one(t & 1, d);
+				__builtin_amdgcn_sched_barrier(0);
+				mf_fs(use, idx++);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			{ const bool adv = fetched + 1 < nkt; dma_advance(adv); fetched += adv ? 1 : 0; }
+#pragma unroll
+			for (int m = KK * NU + NDMA; m < KK * NM; m++) mf_fs(use, m);
+			__builtin_amdgcn_sched_barrier(0);
+			if constexpr (G7) { const bool wrap = w7_tap == 8; w7_g += wrap ? 1 : 0; w7_tap = wrap ? 0 : w7_tap + 1; }
 		};
 		if (nkt > 0) {
-			fetch_slab(0);
-			if (GATHER == 5 || GATHER == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row-end loads are asm: hipcc does not wait for them)
-			apply_fix(0);
-			fetch_slab(1);
-			if (GATHER == 5 || GATHER == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			apply_fix(1);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (GATHER == 5 || GATHER == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row-end chunks' LDS writes
-			__builtin_amdgcn_s_barrier();
+			if constexpr (G7) {   // the window of channel group 0, whole; group 1 follows during the first slabs
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-			for (int u = 0; u < NU; u++) read_unit(0, 0, u, P);
-			for (int t = 0; t < nkt; t++) slab(t);
+				for (int i = 0; i < W7_PW; i++)
+					if (wave + 4 * i < W7_NI) {
+						const int off = window_chunk_offset<W7_PL, GWS>((wave + 4 * i) * 64 + lane, w7_i0, p.g_H, p.g_HWo, w7_base);
+						const float* src = off >= 0 ? w7_img + off : w7_zero;
+						__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + 2 * A_SZ + 4 + (wave + 4 * i) * 256), 16, 0, 0);
+					}
+#endif
+				w7_cur = 0; w7_ad[0] = w7_addr(0, 0);
+			}
+			fetch_slab(0);
+			fetch_slab(1);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			if constexpr (FS) {
+#pragma unroll
+				for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+					for (int u = 0; u < NU; u++) read_unit(0, kk, u, F0[kk]);
+				int t = 0;
+				for (; t + 1 < nkt; t += 2) { slab_fs(t, F0, F1); slab_fs(t + 1, F1, F0); }
+				if (t < nkt) slab_fs(t, F0, F1);      // an odd number of slabs
+			} else {
+#pragma unroll
+				for (int u = 0; u < NU; u++) read_unit(0, 0, u, P);
+				for (int t = 0; t < nkt; t++) slab(t);
+			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetches of the last slab
 		}
 		store_tile();

@@ -42,9 +42,6 @@ inline const float* zero_word() { return reinterpret_cast<const float*>(ctx().ti
 //   mode 3: mode 1 on a zero-padded image copy (stride 1): no bounds checks, 16-byte DMA;  tables hold padded offsets
 //   mode 4: mode 2 transposed on a padded copy (stride 1): M = taps, N = rows of A (= del_y [image][N][HWo]), C [N][M] = the weight gradient
 // tables: {element offset, y | x << 16}.  Needs K % 16 == 0 (mode 2: HWo % 16 == 0), A 16-byte aligned with lda % 4 == 0.
-//   modes 5 / 6: modes 3 / 4 straight from the image, no padded copy (stride 1; whole 128-wide tiles on the half-slab pipeline: gather_whole_tiles);
-//           mode 5 contracts tap-major (A [M][(tap, channel)], ktab per 16-deep slab), mode 6: ktab = pixels {r, i | j << 16}, ntab = taps
-bool gather_whole_tiles(int mode, int M, int N);                       // the half-slab pipeline takes this M x N (modes 3 - 6)
 int gather3_splits(int M, int N, int K);                               // ... of a mode-3 product (forward / data gradient on few tiles)
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo);   // K splits (= slabs of M*N floats in the workspace) gather_gemm will use
 struct GatherEpilogue { const float* bias; int bias_stride; const float* add; float* out2; };   // mode 3: out = product + bias[image * stride + row]; out2 = out + add

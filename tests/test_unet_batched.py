@@ -160,3 +160,9 @@ def test_batched_attention_block(pkg, cfg):
         sums = {n: g1[n].astype(np.float64) for n in g1} if sums is None else {n: sums[n] + g1[n] for n in g1}
     for n in sums:
         assert np.linalg.norm(gr[n] - sums[n]) <= 2e-5 * np.linalg.norm(sums[n]) + 1e-12, (cfg, n)
+
+
+def test_batched_resnet_block_on_the_window_kernel(pkg):
+    """32 images of 128 channels at 32 x 32: 256 tiles of 128 x 128, one per CU -- the stride-1 3x3 convolutions run straight from the image with the window in
+    LDS (gather mode 7), the time-embedding bias per image and the residual sum applied where the tiles are stored.  Same checks as the cases above."""
+    test_batched_resnet_block(pkg, (32, 128, 128, 32, 32, 32))
