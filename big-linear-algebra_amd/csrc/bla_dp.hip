@@ -56,6 +56,7 @@ struct DpKernelArgs {
 	unsigned* flags_b;
 	unsigned per4;                        // float4 groups per slice: slice r = [r * per4, min((r + 1) * per4, n4))
 	long long timeout_ticks;
+	int flags_posted;                     // the last gradient kernel of the step has already told the peers (DoneHook): no push here
 };
 
 __device__ __forceinline__ float4 load16_nt(const float* base, size_t i4) {
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) dp_allreduce_twoshot_kernel(DpKernelArgs 
 	const unsigned epoch = a.state[0] + 1;
 	if (threadIdx.x == 0) { s_fail = 0; s_last = 0; }
 	__syncthreads();
-	if (blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)   // (the system-scope release is the fence)
+	if (!a.flags_posted && blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)   // (the system-scope release is the fence)
 		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	bool ok = wait_flags(a.flags, a.world, a.rank, epoch, &s_fail, a.timeout_ticks);
 	// phase A: my slice of every bucket, summed in rank order -> reduced buffer (for the peers) and my own out / target
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256) dp_allreduce_kernel(DpKernelArgs a) {
 	if (threadIdx.x == 0) s_fail = 0;
 	__syncthreads();
 	// this rank's gradient kernels finished before this launch; the system-scope release makes their bytes visible to the peers
-	if (blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)
+	if (!a.flags_posted && blockIdx.x == 0 && (int)threadIdx.x < a.world && (int)threadIdx.x != a.rank)
 		__hip_atomic_store(a.peer_flags[threadIdx.x] + a.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	if ((int)threadIdx.x < a.world && (int)threadIdx.x != a.rank) {   // (a rank's own data is ordered by its stream: no flag to itself)
 		const long long t0 = wall_clock64();
@@ -243,6 +244,7 @@ struct bla_dp {
 	bool connected;
 	unsigned resident_blocks;    // workgroups of the two-shot kernel this device holds at once (occupancy x CUs), measured at create
 	long long timeout_ticks;
+	DoneHook* hook;              // device copy of the "gradients ready" post for the last gradient kernel (built by connect; NULL for one rank)
 	unsigned long long steps;    // data-parallel steps issued through this object: the trainers take their bucket parity from here
 };
 
@@ -301,6 +303,7 @@ bla_status bla_dp_create(bla_dp** out, int rank, int world, size_t count) {
 	for (int r = 0; r < kMaxWorld; r++) { dp->peer[r] = nullptr; dp->peer_flags[r] = nullptr; dp->peer_ipc[r] = false; }
 	dp->peer[rank] = dp->base; dp->peer_flags[rank] = dp->flags;
 	dp->connected = world == 1;
+	dp->hook = nullptr;
 	dp->steps = 0;
 	// The two-shot kernel's second phase waits for workgroups of the same launch (here and on the peers): its grid must be resident at once.  What
 	// "at once" allows is asked of the runtime (occupancy of that kernel x CUs), not assumed.
@@ -326,6 +329,7 @@ bla_status bla_dp_destroy(bla_dp* dp) {
 	(void)hipFree(dp->base);
 	(void)hipFree(dp->flags);
 	(void)hipFree(dp->state);
+	if (dp->hook) (void)hipFree(dp->hook);
 	delete dp;
 	if (ctx().ready) (void)hipSetDevice(ctx().device);
 	return BLA_OK;
@@ -377,6 +381,19 @@ bla_status bla_dp_connect(bla_dp* dp, const void* handles) {
 		}
 		dp->peer[r] = p; dp->peer_flags[r] = f; dp->peer_ipc[r] = true;
 	}
+	// the "gradients ready" post for the last gradient kernel of a step: arrival counter = state[4], epoch = state[0], the peers' flag arrays A
+	if (dp->world > 1 && !dp->hook) {
+		DoneHook h;
+		memset(&h, 0, sizeof h);
+		h.arrive = dp->state + 4; h.epoch = dp->state; h.world = dp->world; h.rank = dp->rank;
+		for (int r = 0; r < dp->world; r++) h.peer_flags[r] = (unsigned*)dp->peer_flags[r];
+		void* d = nullptr;
+		BLA_HIP(hipMalloc(&d, sizeof h));
+		hipError_t e = hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx().stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+		if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "upload of the gradients-ready hook"); }
+		dp->hook = (DoneHook*)d;
+	}
 	dp->connected = true;
 	if (ctx().ready) (void)hipSetDevice(ctx().device);
 	return BLA_OK;
@@ -389,6 +406,17 @@ size_t bla_dp_count(const bla_dp* dp) { return dp ? dp->count : 0; }
  * (if d_target).  Collective: every rank enqueues the same sequence of calls with the same parity; parities alternate.
  * Asynchronous on `stream`, capturable into a hipGraph (the epoch lives in device memory). */
 bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha) {
+	return bla::dp_allreduce(dp, stream, parity, d_out, d_target, alpha, false);
+}
+
+}  // extern "C"
+
+const DoneHook* bla::dp_done_hook(bla_dp* dp) {
+	static const bool off = [] { const char* e = getenv("BLA_DP_POST"); return e && e[0] == '0'; }();   // BLA_DP_POST=0: the exchange launch pushes the flags itself
+	return dp && !off ? dp->hook : nullptr;
+}
+
+bla_status bla::dp_allreduce(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha, bool flags_posted) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(dp, BLA_ERR_INVALID, "null exchange");
@@ -405,6 +433,7 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 	a.n4 = (unsigned)((dp->count + 3) / 4); a.count = (unsigned)dp->count;
 	a.world = dp->world; a.rank = dp->rank;
 	a.timeout_ticks = dp->timeout_ticks;
+	a.flags_posted = flags_posted ? 1 : 0;
 	unsigned cus = (unsigned)(ctx().num_cus > 0 ? ctx().num_cus : 256);
 	// Every workgroup of an exchange launch spins until the peers' launches have shown up, so all launches of a group must be resident
 	// at once.  One rank per GPU: always true.  Several ranks REHEARSING on one GPU (tests, BLA_BENCH_SHARE_GPU) share its workgroup
@@ -437,6 +466,8 @@ bla_status bla_dp_allreduce_f32(bla_dp* dp, void* stream, int parity, float* d_o
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
+
+extern "C" {
 
 /* 0 = healthy; 1 = a wait for a peer's flag timed out in some earlier exchange (the sums of that exchange were skipped).
  * Synchronises the device. */

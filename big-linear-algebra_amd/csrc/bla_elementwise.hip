@@ -57,6 +57,25 @@ __global__ void __launch_bounds__(kThreads) ew_kernel(float* __restrict__ a, con
 	for (size_t j = n4 * 4 + tid; j < n; j += stride) a[j] = ew_apply<OP>(a[j], BINARY ? b[j] : 0.f, f);
 }
 
+// Two reads and one write per element (matrix_add / hadamard / axpy, lib/matrix.c:65-69,95-103): two adjacent float4 per lane per stream (32 bytes) on a
+// grid of two workgroups per CU.  Measured at 8192 x 8192 (round 3, tools/ew_bench.py): 5.32 TB/s algorithmic in the one-float4 grid-stride form below,
+// 5.24 with non-temporal stores of the written stream, 5.36 with 32 bytes per lane, 5.40 with both, 5.52 with 32 bytes per lane on two workgroups per CU
+// (this form); the one-read-one-write ops sit at 6.4 - 6.6 on the same part.
+template <int OP>
+__global__ void __launch_bounds__(kThreads) ew_binary_kernel(float* __restrict__ a, const float* __restrict__ b, float f, size_t n) {
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	float4* a4 = reinterpret_cast<float4*>(a);
+	const float4* b4 = reinterpret_cast<const float4*>(b);
+	const size_t n4 = n / 4, n8 = n4 / 2;
+	auto op4 = [&](float4 x, float4 y) { return make_float4(ew_apply<OP>(x.x, y.x, f), ew_apply<OP>(x.y, y.y, f), ew_apply<OP>(x.z, y.z, f), ew_apply<OP>(x.w, y.w, f)); };
+	for (size_t i = tid; i < n8; i += stride) {
+		const float4 x0 = a4[2 * i], x1 = a4[2 * i + 1], y0 = b4[2 * i], y1 = b4[2 * i + 1];
+		a4[2 * i] = op4(x0, y0); a4[2 * i + 1] = op4(x1, y1);
+	}
+	for (size_t i = n8 * 2 + tid; i < n4; i += stride) a4[i] = op4(a4[i], b4[i]);
+	for (size_t j = n4 * 4 + tid; j < n; j += stride) a[j] = ew_apply<OP>(a[j], b[j], f);
+}
+
 template <int OP, bool BINARY>
 static bla_status launch_ew(void* stream, float* a, const float* b, float f, size_t n) {
 	bla_status st = require_ready();
@@ -64,6 +83,12 @@ static bla_status launch_ew(void* stream, float* a, const float* b, float f, siz
 	if (n == 0) return BLA_OK;
 	BLA_REQUIRE(a && (!BINARY || b), BLA_ERR_INVALID, "null operand");
 	int vec_ok = ((uintptr_t)a % 16 == 0) && (!BINARY || (uintptr_t)b % 16 == 0);
+	if (BINARY && vec_ok) {
+		const size_t need = (n / 8 + kThreads - 1) / kThreads, cap = 2 * (size_t)(ctx().num_cus > 0 ? ctx().num_cus : 256);
+		hipLaunchKernelGGL((ew_binary_kernel<OP>), dim3((unsigned)(need < 1 ? 1 : (need > cap ? cap : need))), dim3(kThreads), 0, pick_stream(stream), a, b, f, n);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
+	}
 	hipLaunchKernelGGL((ew_kernel<OP, BINARY>), dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, pick_stream(stream), a, b, f, n, vec_ok);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
@@ -395,9 +420,84 @@ __global__ void __launch_bounds__(kThreads) softmax_cols_apply_kernel(float* __r
 	}
 }
 
+// Up to 4096 rows (cols % 16 == 0): a 1024-thread workgroup keeps its strip of 16 columns IN REGISTERS -- thread (row group t / 4, column quad t % 4) holds
+// rows t / 4 + 256 i as float4 -- so the matrix is read once and written once (8 bytes per element, the algorithmic count; the streaming form above
+// reads it twice: 12).  Column maximum and sum of exponentials: each thread over its own rows, the 16 lanes of a wave that share a column quad by
+// shuffles, the 16 waves through LDS in wave order.  The strips are dealt so that neighbours (which share 128-byte lines: a strip's row segment is 64 bytes)
+// are neighbours in one XCD's dispatch order.
+template <int RPT>
+__global__ void __launch_bounds__(1024) softmax_cols_strip_kernel(float* __restrict__ d, int rows, int cols, const float* __restrict__ y, float scale,
+                                                                   float* __restrict__ grad) {
+	__shared__ float sh[2][16][16];   // [max | sum][wave][column of the strip]
+	const int t = threadIdx.x, quad = t & 3, rg = t >> 2, wave = t >> 6, lane = t & 63;
+	const int strips = cols / 16, per_xcd = strips / 8;
+	const int strip = (strips % 8 == 0) ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+	float* base = d + (size_t)strip * 16 + quad * 4;
+	float4 v[RPT];
+#pragma unroll
+	for (int i = 0; i < RPT; i++) {
+		const int r = rg + 256 * i;
+		v[i] = r < rows ? *reinterpret_cast<const float4*>(base + (size_t)r * cols) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+	}
+	float4 m = v[0];
+#pragma unroll
+	for (int i = 1; i < RPT; i++) { m.x = fmaxf(m.x, v[i].x); m.y = fmaxf(m.y, v[i].y); m.z = fmaxf(m.z, v[i].z); m.w = fmaxf(m.w, v[i].w); }
+#pragma unroll
+	for (int o = 4; o < 64; o <<= 1) {   // the 16 lanes of this wave with the same column quad
+		m.x = fmaxf(m.x, __shfl_xor(m.x, o, 64)); m.y = fmaxf(m.y, __shfl_xor(m.y, o, 64)); m.z = fmaxf(m.z, __shfl_xor(m.z, o, 64)); m.w = fmaxf(m.w, __shfl_xor(m.w, o, 64));
+	}
+	if (lane < 4) *reinterpret_cast<float4*>(&sh[0][wave][lane * 4]) = m;
+	__syncthreads();
+	float4 M = *reinterpret_cast<const float4*>(&sh[0][0][quad * 4]);
+#pragma unroll
+	for (int w = 1; w < 16; w++) {
+		const float4 q = *reinterpret_cast<const float4*>(&sh[0][w][quad * 4]);
+		M.x = fmaxf(M.x, q.x); M.y = fmaxf(M.y, q.y); M.z = fmaxf(M.z, q.z); M.w = fmaxf(M.w, q.w);
+	}
+	float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+	for (int i = 0; i < RPT; i++) {      // exp(-inf) = 0 for the rows past the end
+		v[i].x = expf(v[i].x - M.x); v[i].y = expf(v[i].y - M.y); v[i].z = expf(v[i].z - M.z); v[i].w = expf(v[i].w - M.w);
+		sum.x += v[i].x; sum.y += v[i].y; sum.z += v[i].z; sum.w += v[i].w;
+	}
+#pragma unroll
+	for (int o = 4; o < 64; o <<= 1) {
+		sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64); sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+	}
+	if (lane < 4) *reinterpret_cast<float4*>(&sh[1][wave][lane * 4]) = sum;
+	__syncthreads();
+	float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+	for (int w = 0; w < 16; w++) {       // wave order: the same total in every thread
+		const float4 q = *reinterpret_cast<const float4*>(&sh[1][w][quad * 4]);
+		S.x += q.x; S.y += q.y; S.z += q.z; S.w += q.w;
+	}
+#pragma unroll
+	for (int i = 0; i < RPT; i++) {
+		const int r = rg + 256 * i;
+		if (r < rows) {
+			const float4 p = make_float4(v[i].x / S.x, v[i].y / S.y, v[i].z / S.z, v[i].w / S.w);   // exp(x - max) / sum, lib/util.c:26-31
+			const size_t off = (size_t)r * cols;
+			*reinterpret_cast<float4*>(base + off) = p;
+			if (grad) {
+				const float4 tt = *reinterpret_cast<const float4*>(y + (size_t)strip * 16 + quad * 4 + off);
+				*reinterpret_cast<float4*>(grad + (size_t)strip * 16 + quad * 4 + off) = make_float4((p.x - tt.x) * scale, (p.y - tt.y) * scale, (p.z - tt.z) * scale, (p.w - tt.w) * scale);
+			}
+		}
+	}
+}
+
 static bla_status softmax_cols_dispatch(void* stream, float* d, int rows, int cols, const float* y, float scale, float* grad) {
 	hipStream_t s = pick_stream(stream);
 	const bool al = ((uintptr_t)d | (uintptr_t)y | (uintptr_t)grad) % 16 == 0;
+	if (rows >= 256 && rows <= 4096 && cols % 16 == 0 && cols >= 1024 && al) {   // (enough strips to fill the chip: 64 of them are a quarter of the CUs)
+		const dim3 grid((unsigned)(cols / 16));
+		if (rows <= 1024) hipLaunchKernelGGL(softmax_cols_strip_kernel<4>, grid, dim3(1024), 0, s, d, rows, cols, y, scale, grad);
+		else if (rows <= 2048) hipLaunchKernelGGL(softmax_cols_strip_kernel<8>, grid, dim3(1024), 0, s, d, rows, cols, y, scale, grad);
+		else hipLaunchKernelGGL(softmax_cols_strip_kernel<16>, grid, dim3(1024), 0, s, d, rows, cols, y, scale, grad);
+		BLA_HIP(hipGetLastError());
+		return BLA_OK;
+	}
 	if (rows >= 256 && cols % 4 == 0 && al) {
 		unsigned vx = (unsigned)((cols / 4 + kThreads - 1) / kThreads);
 		int chunks = (int)((ctx().num_cus > 0 ? ctx().num_cus : 256) / vx);   // one workgroup per CU, as for the column sums

@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_kernel(GemmArgs p) {
 // together they overlap instead of queueing, which takes two ~5 us launches off the step's critical path.
 // Each product brings its own tile size (GemmArgs::wsk_tile).
 template <bool AKC1, bool BKC1, bool AKC2, bool BKC2>
-__global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, GemmArgs q, int tiles_p) {
+__global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, GemmArgs q, int tiles_p, const DoneHook* done) {
 	__shared__ __attribute__((aligned(16))) WskShared sh;
 	if ((int)blockIdx.x < tiles_p) {
 		if (p.wsk_tile == 16) wsk_body<16, AKC1, BKC1, true, true>(p, (int)blockIdx.x, 0, sh);
@@ -478,6 +478,22 @@ __global__ void __launch_bounds__(256) gemm_f32_wsk_pair_kernel(GemmArgs p, Gemm
 	} else {
 		if (q.wsk_tile == 16) wsk_body<16, AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
 		else wsk_body<32, AKC2, BKC2, true, true>(q, (int)blockIdx.x - tiles_p, 0, sh);
+	}
+	if (done) {   // the last gradient kernel of a data-parallel step: the workgroup that finishes last tells the peers (DoneHook, bla_internal.h)
+		__shared__ int s_last;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__threadfence_system();                          // ... and written back: the peers read over xGMI from memory
+			s_last = __hip_atomic_fetch_add(done->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+		}
+		__syncthreads();
+		if (s_last) {
+			if (threadIdx.x == 0) *done->arrive = 0;
+			const unsigned epoch = *done->epoch + 1;      // (the previous exchange finished before this launch: stream order)
+			if ((int)threadIdx.x < done->world && (int)threadIdx.x != done->rank)
+				__hip_atomic_store(done->peer_flags[threadIdx.x] + done->rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 }
 
@@ -905,7 +921,12 @@ bla_status bla_gemm_f32(void* stream, int transa, int transb, int m, int n, int 
 
 /* Two INDEPENDENT products (neither reads what the other writes) issued together.  When both are latency-bound shapes of the
  * wave-split-K kernel they share one launch and overlap; otherwise this is two bla_gemm_f32 calls. */
-bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q) {
+bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q) { return gemm_pair_with_hook(stream, p, q, nullptr, nullptr); }
+
+}  // extern "C"
+
+bla_status bla::gemm_pair_with_hook(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q, const DoneHook* d_hook, bool* posted) {
+	if (posted) *posted = false;
 	BLA_REQUIRE(p && q, BLA_ERR_INVALID, "null descriptor");
 	WskPlan pp = {}, pq = {};
 	const bool try_pair = g_force_config < 0 && g_force_split <= 0;
@@ -921,13 +942,14 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 		// TN beside TN = the attention block's Q and K projections, ...)
 		const dim3 grid((unsigned)(tp + tq));
 		const int combo = (pp.akc ? 8 : 0) | (pp.bkc ? 4 : 0) | (pq.akc ? 2 : 0) | (pq.bkc ? 1 : 0);
-#define BLA_PAIR_CASE(I) case I: hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<((I) & 8) != 0, ((I) & 4) != 0, ((I) & 2) != 0, ((I) & 1) != 0>), grid, dim3(256), 0, s, pp.a, pq.a, tp); break
+#define BLA_PAIR_CASE(I) case I: hipLaunchKernelGGL((gemm_f32_wsk_pair_kernel<((I) & 8) != 0, ((I) & 4) != 0, ((I) & 2) != 0, ((I) & 1) != 0>), grid, dim3(256), 0, s, pp.a, pq.a, tp, d_hook); break
 		switch (combo) {
 			BLA_PAIR_CASE(0); BLA_PAIR_CASE(1); BLA_PAIR_CASE(2); BLA_PAIR_CASE(3); BLA_PAIR_CASE(4); BLA_PAIR_CASE(5); BLA_PAIR_CASE(6); BLA_PAIR_CASE(7);
 			BLA_PAIR_CASE(8); BLA_PAIR_CASE(9); BLA_PAIR_CASE(10); BLA_PAIR_CASE(11); BLA_PAIR_CASE(12); BLA_PAIR_CASE(13); BLA_PAIR_CASE(14); BLA_PAIR_CASE(15);
 		}
 #undef BLA_PAIR_CASE
 		e = hipGetLastError();
+		if (posted && e == hipSuccess) *posted = d_hook != nullptr;
 		snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_wsk_pair_%c%c+%c%c_%dx%d+%dx%d", pp.akc ? 'n' : 't', pp.bkc ? 't' : 'n', pq.akc ? 'n' : 't',
 		         pq.bkc ? 't' : 'n', tp, pp.a.wsk_tile, tq, pq.a.wsk_tile);
 	} else {
@@ -937,6 +959,8 @@ bla_status bla_gemm_pair_f32(void* stream, const bla_gemm_desc* p, const bla_gem
 	if (e != hipSuccess) return hip_fail(e, "gemm_f32_wsk pair launch");
 	return BLA_OK;
 }
+
+extern "C" {
 
 /* C_i = op(A_i) op(B_i) for i < batch, operand i at base + i * stride (stride 0 = shared).  Latency-bound shapes (what a self-attention block over
  * a batch of images is made of) run as ONE launch of the wave-split-K kernel; anything else is issued set by set.  ep (alpha / beta, bias_row,

@@ -61,6 +61,25 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
                                 int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend);
 
+// "My gradients are ready", posted by the LAST gradient kernel of a data-parallel step instead of by the exchange launch behind it (every
+// step paid a launch boundary before any peer could start reading).  The block lives in device memory (built by bla_dp_connect); a launch that is
+// handed it counts its workgroups in, and the last one to finish stores epoch + 1 into every peer's flag word for this rank -- each workgroup after
+// its own s_waitcnt vmcnt(0) + barrier + system-scope release fence, the last arriver with an acquire on the count and system-scope release stores
+// (the two-shot exchange's publish protocol).
+struct DoneHook {
+	unsigned* arrive;          // arrival counter, zero between launches
+	const unsigned* epoch;     // the exchange object's state[0]: epoch of its last finished exchange
+	int world, rank;
+	unsigned* peer_flags[16];  // flag array A in rank p's memory (own slot unused)
+};
+// bla_gemm.hip: bla_gemm_pair_f32 with the hook handed to the pair launch; *posted says whether a launch took it (a pair that falls back to two
+// launches does not)
+bla_status gemm_pair_with_hook(void* stream, const bla_gemm_desc* p, const bla_gemm_desc* q, const DoneHook* d_hook, bool* posted);
+// bla_dp.hip: the device-resident hook of a connected exchange object (NULL for a single rank); the exchange of `parity` with the flag push left
+// to whoever took the hook
+const DoneHook* dp_done_hook(bla_dp* dp);
+bla_status dp_allreduce(bla_dp* dp, void* stream, int parity, float* d_out, float* d_target, float alpha, bool flags_posted);
+
 // bla_dp.hip: identity of an exchange object that survives address reuse (a destroyed and re-created object never has the same id)
 unsigned long long dp_identity(const bla_dp* dp);
 // gradient-bucket parity of the next data-parallel step through this exchange object / count one step (several trainers -- the full-batch

@@ -42,211 +42,6 @@ struct bla_mnist_nn {
 
 using namespace bla;
 
-// ---- the per-sample chain of one step in ONE launch ---------------------------------------------------------------------------------
-// Everything between the first layer's activations and the first layer's pre-activation gradient is column-local -- sample k's column of
-// Z2, A2, Z3, A3, dZ3, dZ2 and dZ1 depends on no other sample (model/mnist_nn.c:226-234, 260-268, 273-278, 284-289); only the weight
-// gradients sum over columns.  As separate launches those five products cost ~5 us each of pure launch latency for < 1 us of MFMA work
-// (profiles/r02/mnist*).  Here one workgroup owns 16 columns and walks the whole chain with the intermediate columns in LDS:
-//     A1 cols -> Z2 = W2 A1 + b2, A2 = relu -> Z3 = W3 A2 + b3, A3 = softmax, dZ3 = (A3 - Y) / n0 [+ loss / accuracy] ->
-//     dZ2 = (W3^T dZ3) (.) relu'(Z2) -> dZ1 = (W2^T dZ2) (.) relu'(Z1)
-// on v_mfma_f32_16x16x4_f32 (lane l: index l & 15, k-slot l >> 4; a lane holds 4 consecutive k and MFMA j multiplies element j of every
-// lane, as in the wave-split-K GEMM).  A step is then three launches: the first layer's product, this chain, the three weight gradients.
-namespace {
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kChainMaxN1 = 256, kChainMaxN2 = 128;
-struct ChainArgs {
-	const float *A1, *Z1, *W2, *b2, *W3, *b3, *Y;
-	float *Z2, *A2, *Z3, *A3, *dZ3, *dZ2, *dZ1;
-	int n1, n2, n3, B, backward;
-	float gscale;
-	double* sm_loss; unsigned* sm_correct;
-};
-
-// Every weight fragment a stage needs is fetched in ONE batch before the stage's MFMAs (fully unrolled register arrays, compile-time
-// bounds): a load in front of each MFMA group made the chain 33 us of dependent round trips; batched, a stage costs one round trip.
-__global__ void __launch_bounds__(256) mnist_chain_kernel(ChainArgs p) {
-	__shared__ __attribute__((aligned(16))) float a1c[16][kChainMaxN1 + 4];    // [column][k]: one ds_read_b128 = 4 consecutive k of a lane's column
-	__shared__ __attribute__((aligned(16))) float a2c[16][kChainMaxN2 + 4];
-	__shared__ __attribute__((aligned(16))) float dz2c[16][kChainMaxN2 + 4];
-	__shared__ __attribute__((aligned(16))) float dz3c[16][20];
-	__shared__ float part[4][16][17];
-	constexpr int C1 = kChainMaxN1 / 16, C2 = kChainMaxN2 / 16;   // 16-deep k chunks of the two hidden widths
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-	const int n0 = blockIdx.x * 16, n1 = p.n1, n2 = p.n2, n3 = p.n3, B = p.B;
-	const int nt2 = n2 / 16, per2 = (nt2 + 3) / 4, nt1 = n1 / 16, per1 = (nt1 + 3) / 4;
-	auto mfma4 = [](const float4& a, const float4& b, f32x4 acc) {
-		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-		acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-		return acc;
-	};
-	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-	// ---- fetch: layer 2's weight rows for this wave's (up to) two row tiles, the output layer's rows for its K chunks, W3^T for dZ2 ----
-	float4 w2a[2][C1];
-#pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int mt = wave * per2 + t;
-		const bool ok = t < per2 && mt < nt2;
-		const float* wrow = p.W2 + (size_t)((ok ? mt : 0) * 16 + li) * n1 + 4 * lq;
-#pragma unroll
-		for (int c = 0; c < C1; c++) w2a[t][c] = (ok && c * 16 < n1) ? *reinterpret_cast<const float4*>(wrow + c * 16) : zero4;
-	}
-	float4 w3a[2];   // chunks wave, wave + 4 of the output layer's contraction
-#pragma unroll
-	for (int u = 0; u < 2; u++) {
-		const int kb = (wave + 4 * u) * 16;
-		w3a[u] = (li < n3 && kb < n2) ? *reinterpret_cast<const float4*>(p.W3 + (size_t)li * n2 + kb + 4 * lq) : zero4;
-	}
-	float4 w3t[2];   // W3^T fragments of the dZ2 tiles: element j = W3[4 lq + j][row]
-#pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int mt = wave * per2 + t;
-		const int r0 = ((t < per2 && mt < nt2) ? mt : 0) * 16;
-		w3t[t].x = 4 * lq + 0 < n3 ? p.W3[(size_t)(4 * lq + 0) * n2 + r0 + li] : 0.f; w3t[t].y = 4 * lq + 1 < n3 ? p.W3[(size_t)(4 * lq + 1) * n2 + r0 + li] : 0.f;
-		w3t[t].z = 4 * lq + 2 < n3 ? p.W3[(size_t)(4 * lq + 2) * n2 + r0 + li] : 0.f; w3t[t].w = 4 * lq + 3 < n3 ? p.W3[(size_t)(4 * lq + 3) * n2 + r0 + li] : 0.f;
-	}
-	float b2v[2][4];   // biases of this lane's rows
-#pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int mt = wave * per2 + t;
-		const int r0 = ((t < per2 && mt < nt2) ? mt : 0) * 16;
-#pragma unroll
-		for (int r = 0; r < 4; r++) b2v[t][r] = p.b2[r0 + 4 * lq + r];
-	}
-	float b3v[16], yv[16];   // output layer: bias and this column's labels (threads 0..15 use them)
-	double loss0 = 0.0; unsigned corr0 = 0;
-#pragma unroll
-	for (int r = 0; r < 16; r++) { b3v[r] = (tid < 16 && r < n3) ? p.b3[r] : 0.f; yv[r] = (tid < 16 && r < n3) ? p.Y[(size_t)r * B + n0 + tid] : 0.f; }
-	if (tid < 16 && p.sm_loss) { loss0 = p.sm_loss[n0 + tid]; corr0 = p.sm_correct[n0 + tid]; }
-	// the 16 columns of A1, transposed into LDS
-	for (int e = tid; e < n1 * 4; e += 256) {
-		const int k = e >> 2, c4 = (e & 3) * 4;
-		const float4 v = *reinterpret_cast<const float4*>(p.A1 + (size_t)k * B + n0 + c4);
-		a1c[c4][k] = v.x; a1c[c4 + 1][k] = v.y; a1c[c4 + 2][k] = v.z; a1c[c4 + 3][k] = v.w;
-	}
-	for (int e = tid; e < 16 * 20; e += 256) (&dz3c[0][0])[e] = 0.f;
-	__syncthreads();
-	// ---- layer 2 (:226-229): row tiles of 16, two per wave at n2 = 128 ----
-	f32x4 z2[2];
-#pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int mt = wave * per2 + t;
-		z2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-		if (t >= per2 || mt >= nt2) continue;
-		const int r0 = mt * 16;
-		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-		for (int c = 0; c < C1; c++)
-			if (c * 16 < n1) acc = mfma4(w2a[t][c], *reinterpret_cast<const float4*>(&a1c[li][c * 16 + 4 * lq]), acc);
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int row = r0 + 4 * lq + r;
-			const float z = acc[r] + b2v[t][r];
-			const float a = z < 0.f ? 0.f : z;
-			p.Z2[(size_t)row * B + n0 + li] = z; p.A2[(size_t)row * B + n0 + li] = a;
-			a2c[li][row] = a;
-			z2[t][r] = z;
-		}
-	}
-	// (the next stages' weights that do not fit beside w2a: W2^T for the first dZ1 tile is fetched now, under the output layer)
-	float4 w2t[2][C2];     // two register sets: tile t + 1 is fetched while tile t multiplies
-	float zm[2][4];        // relu'(Z1) inputs of the tile
-	auto fetch_t = [&](int t, float4 (&w)[C2], float (&m)[4]) {
-		const int mt = wave * per1 + t;
-		const bool ok = t < per1 && mt < nt1;
-		const int r0 = (ok ? mt : 0) * 16;
-		const float* wcol = p.W2 + (size_t)(4 * lq) * n1 + r0 + li;    // W2^T[m][k] = W2[k][m]
-#pragma unroll
-		for (int c = 0; c < C2; c++) {
-			const float* q = wcol + (size_t)(c * 16) * n1;
-			w[c] = (ok && c * 16 < n2) ? make_float4(q[0], q[n1], q[2 * (size_t)n1], q[3 * (size_t)n1]) : zero4;
-		}
-#pragma unroll
-		for (int r = 0; r < 4; r++) m[r] = ok ? p.Z1[(size_t)(r0 + 4 * lq + r) * B + n0 + li] : 0.f;
-	};
-	if (p.backward == 1) fetch_t(0, w2t[0], zm[0]);
-	__syncthreads();
-	// ---- output layer (:231-234, 260-268): one 16 x 16 tile, K cut over the four waves, partial tiles folded in wave order ----
-	{
-		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			const int kb = (wave + 4 * u) * 16;
-			if (kb < n2) acc = mfma4(w3a[u], *reinterpret_cast<const float4*>(&a2c[li][kb + 4 * lq]), acc);
-		}
-#pragma unroll
-		for (int r = 0; r < 4; r++) part[wave][4 * lq + r][li] = acc[r];
-	}
-	__syncthreads();
-	if (tid < 16) {
-		// (fixed trip counts and values fetched up front: a load behind each store -- the compiler must assume they alias -- made this
-		// tail ten dependent round trips long)
-		const int c = tid, col = n0 + tid;
-		float z[16];
-		float mx = -INFINITY;
-#pragma unroll
-		for (int r = 0; r < 16; r++) {
-			z[r] = r < n3 ? ((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c] + b3v[r] : -INFINITY;
-			mx = fmaxf(mx, z[r]);
-		}
-		float e[16], sum = 0.f;
-#pragma unroll
-		for (int r = 0; r < 16; r++) { e[r] = r < n3 ? expf(z[r] - mx) : 0.f; sum += e[r]; }
-		int pred = 0; float best = 0.f, ypred = yv[0]; double loss = 0.0;
-#pragma unroll
-		for (int r = 0; r < 16; r++) {
-			if (r < n3) {
-				const float pr = e[r] / sum;
-				const float g = (pr - yv[r]) * p.gscale;
-				p.Z3[(size_t)r * B + col] = z[r]; p.A3[(size_t)r * B + col] = pr; p.dZ3[(size_t)r * B + col] = g;
-				dz3c[c][r] = g;
-				if (p.sm_loss) {   // loss / accuracy bookkeeping, :237-257 (see the softmax tail of the wave-split-K GEMM)
-					if (pr > best) { best = pr; pred = r; ypred = yv[r]; }
-					if (yv[r] != 0.f) loss += -1.0 * ((double)yv[r] * log((double)pr + 1e-15));
-				}
-			}
-		}
-		(void)pred;
-		if (p.sm_loss) { p.sm_loss[col] = loss0 + loss; p.sm_correct[col] = corr0 + (ypred == 1.f ? 1u : 0u); }
-	}
-	if (!p.backward) return;
-	__syncthreads();
-	// ---- dZ2 = (W3^T dZ3) (.) relu'(Z2) (:273-278): the classes are the contraction (n3 <= 16: one group of four MFMAs) ----
-#pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int mt = wave * per2 + t;
-		if (t >= per2 || mt >= nt2) continue;
-		const int r0 = mt * 16;
-		f32x4 acc = mfma4(w3t[t], *reinterpret_cast<const float4*>(&dz3c[li][4 * lq]), f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int row = r0 + 4 * lq + r;
-			const float v = z2[t][r] > 0.f ? acc[r] : 0.f * acc[r];
-			p.dZ2[(size_t)row * B + n0 + li] = v;
-			dz2c[li][row] = v;
-		}
-	}
-	if (p.backward == 2) return;   // the short chain: dZ1 is a product of its own
-	__syncthreads();
-	// ---- dZ1 = (W2^T dZ2) (.) relu'(Z1) (:284-289): row tiles of 16 over n1, four per wave at n1 = 256 ----
-	auto tile_t = [&](int t, const float4 (&w)[C2], const float (&m)[4]) {
-		const int mt = wave * per1 + t;
-		if (t >= per1 || mt >= nt1) return;
-		const int r0 = mt * 16;
-		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-		for (int c = 0; c < C2; c++)
-			if (c * 16 < n2) acc = mfma4(w[c], *reinterpret_cast<const float4*>(&dz2c[li][c * 16 + 4 * lq]), acc);
-#pragma unroll
-		for (int r = 0; r < 4; r++) p.dZ1[(size_t)(r0 + 4 * lq + r) * B + n0 + li] = m[r] > 0.f ? acc[r] : 0.f * acc[r];
-	};
-	for (int t = 0; t < per1; t += 2) {
-		fetch_t(t + 1, w2t[1], zm[1]);
-		tile_t(t, w2t[0], zm[0]);
-		fetch_t(t + 2, w2t[0], zm[0]);
-		tile_t(t + 1, w2t[1], zm[1]);
-	}
-}
-}  // namespace
 
 static bla_status dev_alloc(bla_mnist_nn* nn, float** p, size_t floats) {
 	void* q = nullptr;
@@ -362,7 +157,8 @@ bla_status bla_mnist_nn_activation(bla_mnist_nn* nn, int which, float** d_ptr, i
 /* Forward + backward for one batch: fills the gradient bucket (un-scaled sums over the batch columns).
  * d_x_raw: [n0][B] pixels 0..255 (scaled by 1/255.0F here, model/mnist_nn.c:218); d_y: one-hot [n3][B].
  * NULL for either means "use the trainer's resident input / label buffer". */
-static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads);
+static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads,
+                                        const DoneHook* hook = nullptr, bool* posted = nullptr);
 
 bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode) {
 	BLA_REQUIRE(nn, BLA_ERR_INVALID, "null trainer");
@@ -371,20 +167,6 @@ bla_status bla_mnist_nn_forward_backward(bla_mnist_nn* nn, void* stream, const f
 
 /* Z1 = W1 (x / 255) + b1, A1 = relu; Z2, A2 likewise; Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) / n0; with the
  * loss / accuracy accumulators fed from the output layer's launch when enabled (model/mnist_nn.c:218-268). */
-// 0: off; 1: the whole chain (layer 2, output layer, dZ2, dZ1); 2: the short chain (layer 2, output layer + softmax + loss gradient, dZ2 -- W2 is
-// streamed once, dZ1 stays a product beside dW3)
-static int can_chain(const bla_mnist_nn* nn) {
-	// OFF unless BLA_MNIST_CHAIN=1: measured SLOWER than the launches it replaces (chain 31 us + first layer 6.4 + grouped weight gradients 8.4 =
-	// 45.8 us per step against 32.0 us for six launches).  Every workgroup has to stream all of W2 twice (256 KB through ONE CU's memory path),
-	// and only batch / 16 = 16 CUs work; the five separate launches spread the same bytes over the whole chip.  Kept (and tested) as the
-	// record of that experiment; the three-product grouped launch it brought along is used by nothing else yet.  BLA_MNIST_CHAIN=2, the short chain
-	// (W2 streamed once, dZ1 left to a product: four launches per step), is no better: 43.6 us -- the chain launch itself takes ~27 us whatever it
-	// leaves out, i.e. it is the 16-workgroup forward part (128 KB of W2 into the registers of ONE CU per workgroup) that is slow, not dZ1.
-	static const int mode = [] { const char* e = getenv("BLA_MNIST_CHAIN"); return e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 0); }();
-	const int n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
-	return (n1 % 16 == 0 && n1 <= kChainMaxN1 && n2 % 16 == 0 && n2 <= kChainMaxN2 && n3 <= 16 && B % 16 == 0 && nn->n[0] % 4 == 0) ? mode : 0;
-}
-
 static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x_raw, const float* d_y, bool with_backward) {
 	const int n0 = nn->n[0], n1 = nn->n[1], n2 = nn->n[2], n3 = nn->n[3], B = nn->batch;
 	float *W1 = nn->params + nn->off[0], *b1 = nn->params + nn->off[1], *W2 = nn->params + nn->off[2], *b2 = nn->params + nn->off[3];
@@ -394,13 +176,6 @@ static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x
 	bla_gemm_epilogue ep = {};
 	ep.alpha = xs; ep.bias_row = b1; ep.pre_act = nn->z1; ep.ld_pre = B; ep.act = BLA_ACT_RELU;
 	st = bla_gemm_f32(s, 0, 0, n1, B, n0, W1, n0, d_x_raw, B, nn->a1, B, &ep); if (st) return st;         // :221-224
-	if (can_chain(nn)) {   // everything column-local that follows, forward and backward, in one launch
-		ChainArgs c = {nn->a1, nn->z1, W2, b2, W3, b3, d_y, nn->z2, nn->a2, nn->z3, nn->a3, nn->dz3, nn->dz2, nn->dz1, n1, n2, n3, B, with_backward ? can_chain(nn) : 0,
-		               (float)(1 / (double)n0), nn->metrics_on ? nn->m_loss : nullptr, nn->metrics_on ? nn->m_correct : nullptr};
-		hipLaunchKernelGGL(mnist_chain_kernel, dim3(B / 16), dim3(256), 0, s, c);
-		BLA_HIP(hipGetLastError());
-		return BLA_OK;
-	}
 	ep.alpha = 1.f; ep.bias_row = b2; ep.pre_act = nn->z2;
 	st = bla_gemm_f32(s, 0, 0, n2, B, n1, W2, n1, nn->a1, B, nn->a2, B, &ep); if (st) return st;          // :226-229
 	// output layer: Z3 = W3 A2 + b3, A3 = softmax per column, dZ3 = (A3 - Y) * (1/n0)   (:231-234,260-268;
@@ -418,7 +193,11 @@ static bla_status forward_pass(bla_mnist_nn* nn, hipStream_t s, const float* d_x
 	return BLA_OK;
 }
 
-static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads) {
+// hook: the data-parallel step's "gradients ready" post -- handed to the LAST gradient launch (the {dW2 | dW1} pair), whose last workgroup tells the
+// peers; *posted says whether that happened (otherwise the exchange launch pushes the flags itself, as before)
+static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const float* d_x_raw, const float* d_y, int colsum_mode, float* grads, const DoneHook* hook,
+                                        bool* posted) {
+	if (posted) *posted = false;
 	bla_status st = require_ready();
 	if (st) return st;
 	if (!d_x_raw) d_x_raw = nn->x_raw;
@@ -439,25 +218,6 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	const bool fuse_db = colsum_mode == BLA_COLSUM_INTENDED;   // true row sums ride along the dW products
 
 	st = forward_pass(nn, s, d_x_raw, d_y, true); if (st) return st;
-	const int chain = can_chain(nn);
-	if (chain == 1) {
-		// dZ2 and dZ1 came out of the chain launch: what is left are the three weight gradients (+ bias gradients = row sums of dZ), one launch
-		bla_gemm_epilogue e3 = {}, e2 = {}, e1 = {};
-		e3.alpha = 1.f; e3.row_sum_a = fuse_db ? db3 : nullptr;
-		e2.alpha = 1.f; e2.row_sum_a = fuse_db ? db2 : nullptr;
-		e1.alpha = xs; e1.row_sum_a = fuse_db ? db1 : nullptr;
-		bla_gemm_desc d[3] = {{0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, dW3, n2, &e3},        // :267-271
-		                      {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &e2},        // :279-282
-		                      {0, 1, n1, n0, B, nn->dz1, B, d_x_raw, B, dW1, n0, &e1}};      // :290-293 (the 1/255 of :218 folded into alpha)
-		st = bla_gemm_group_f32(s, d, 3); if (st) return st;
-		if (!fuse_db) {
-			st = bla_col_sum_f32(s, nn->dz3, n3, B, db3, colsum_mode); if (st) return st;
-			st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st;
-			st = bla_col_sum_f32(s, nn->dz1, n1, B, db1, colsum_mode); if (st) return st;
-		}
-		return BLA_OK;
-	}
-
 	// (Measured and not kept: running the layer-3 / layer-2 weight-gradient products on a side stream -- parallel branches of
 	// the captured graph -- to take two launches off the critical path.  The cross-queue dependencies cost more than the
 	// launches: 69.6 us per step instead of 56.)
@@ -465,7 +225,7 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	// reference runs all five one after the other, :267-293), and putting the small dW2 beside the large dW1 hides it completely.
 	bla_gemm_epilogue em = {};
 	em.alpha = 1.f; em.relu_mask = nn->z2; em.ld_mask = B;
-	if (chain != 2) { st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st; }   // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278 (the short chain made it)
+	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em); if (st) return st;   // dZ2 = (W3^T dZ3) (.) relu'(Z2), :273-278
 	bla_gemm_epilogue eg = {};
 	eg.alpha = 1.f; eg.row_sum_a = fuse_db ? db3 : nullptr;
 	bla_gemm_epilogue em1 = {};
@@ -482,7 +242,7 @@ static bla_status forward_backward_into(bla_mnist_nn* nn, void* stream, const fl
 	{
 		bla_gemm_desc d2 = {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, dW2, n1, &eg2};      // dW2, :279-282
 		bla_gemm_desc d1 = {0, 1, n1, n0, B, nn->dz1, B, d_x_raw, B, dW1, n0, &eg1};     // dW1 (the 1/255 of :218 folded into alpha), :290-293
-		st = bla_gemm_pair_f32(s, &d2, &d1); if (st) return st;
+		st = gemm_pair_with_hook(s, &d2, &d1, fuse_db ? hook : nullptr, posted); if (st) return st;   // (with separate bias sums behind it, it is not the last launch)
 	}
 	if (!fuse_db) {
 		st = bla_col_sum_f32(s, nn->dz2, n2, B, db2, colsum_mode); if (st) return st;
@@ -528,19 +288,9 @@ static bla_status fused_update_step(bla_mnist_nn* nn, hipStream_t s, float lr, c
 	const float xs = 1 / 255.0F;
 	bla_status st = forward_pass(nn, s, x, y, true);
 	if (st) return st;
-	const int chain = can_chain(nn);
-	if (chain == 1) {   // the three updates W_l += lr dZ_l A_{l-1}^T, b_l += lr rowsum(dZ_l) in one launch (the chain no longer reads W2 / W3)
-		bla_gemm_epilogue u3 = {}, u2 = {}, u1 = {};
-		u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
-		u2.alpha = lr; u2.beta = 1.f; u2.row_sum_a = b2; u2.row_sum_alpha = lr; u2.row_sum_beta = 1.f;
-		u1.alpha = lr * xs; u1.beta = 1.f; u1.row_sum_a = b1; u1.row_sum_alpha = lr; u1.row_sum_beta = 1.f;
-		bla_gemm_desc d[3] = {{0, 1, n3, n2, B, nn->dz3, B, nn->a2, B, W3, n2, &u3}, {0, 1, n2, n1, B, nn->dz2, B, nn->a1, B, W2, n1, &u2},
-		                      {0, 1, n1, n0, B, nn->dz1, B, x, B, W1, n0, &u1}};
-		return bla_gemm_group_f32(s, d, 3);
-	}
 	bla_gemm_epilogue em2 = {};
 	em2.alpha = 1.f; em2.relu_mask = nn->z2; em2.ld_mask = B;
-	if (chain != 2) { st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st; }   // dZ2: last reader of W3 (or the short chain was)
+	st = bla_gemm_f32(s, 1, 0, n2, B, n3, W3, n2, nn->dz3, B, nn->dz2, B, &em2); if (st) return st;   // dZ2: last reader of W3
 	bla_gemm_epilogue u3 = {}, em1 = {};
 	u3.alpha = lr; u3.beta = 1.f; u3.row_sum_a = b3; u3.row_sum_alpha = lr; u3.row_sum_beta = 1.f;
 	em1.alpha = 1.f; em1.relu_mask = nn->z1; em1.ld_mask = B;
@@ -707,8 +457,9 @@ bla_status bla_mnist_nn_dp_step(bla_mnist_nn* nn, bla_dp* dp, void* stream, floa
 	if (!nn->dp_ready[par]) {
 		BLA_HIP(hipStreamSynchronize(s));
 		BLA_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-		st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par));
-		if (!st) st = bla_dp_allreduce_f32(dp, s, par, nullptr, nn->params, lr);
+		bool posted = false;
+		st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par), dp_done_hook(dp), &posted);
+		if (!st) st = dp_allreduce(dp, s, par, nullptr, nn->params, lr, posted);
 		hipError_t e = hipStreamEndCapture(s, &nn->dp_graph[par]);
 		if (st) { if (e == hipSuccess) (void)hipGraphDestroy(nn->dp_graph[par]); return st; }
 		if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
@@ -730,9 +481,10 @@ bla_status bla_mnist_nn_dp_step_direct(bla_mnist_nn* nn, bla_dp* dp, void* strea
 	BLA_REQUIRE(bla_dp_count(dp) == nn->count, BLA_ERR_SHAPE, "exchange bucket holds %zu floats, the trainer has %zu parameters", bla_dp_count(dp), nn->count);
 	hipStream_t s = pick_stream(stream);
 	const int par = dp_parity(dp);
-	st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par));
+	bool posted = false;
+	st = forward_backward_into(nn, s, nullptr, nullptr, colsum_mode, bla_dp_bucket(dp, par), dp_done_hook(dp), &posted);
 	if (st) return st;
-	st = bla_dp_allreduce_f32(dp, s, par, nullptr, nn->params, lr);
+	st = dp_allreduce(dp, s, par, nullptr, nn->params, lr, posted);
 	if (st) return st;
 	dp_advance(dp);
 	return BLA_OK;

@@ -115,3 +115,20 @@ def test_softmax_grad_fused(dev, ora, rows, cols):
     p = ora.softmax_cols(z.astype(np.float64))
     close(d.numpy(), p, rtol=1e-5, scale=1e-6)
     close(g.numpy(), ora.scale(ora.add(p, -y.astype(np.float64)), 1 / 784), rtol=1e-5, scale=1e-8)
+
+
+@pytest.mark.parametrize("rows,cols", [(300, 1024), (1500, 1040), (4096, 2048), (2049, 1024)])
+def test_softmax_cols_strip_in_registers(dev, ora, rows, cols):
+    """rows <= 4096, cols % 16 == 0, >= 64 strips: a workgroup keeps its 16 columns in registers (one read, one write per element: lib/util.c:15-34 in one
+    pass over memory).  Ragged row counts, a strip count that is not a multiple of 8 (plain strip order), every register depth; with and without the fused
+    loss-gradient tail of model/mnist_nn.c:263-268."""
+    z = uniform(5, (rows, cols), -6, 6, np.float32)
+    y = np.zeros((rows, cols), np.float32); y[np.arange(cols) % rows, np.arange(cols)] = 1
+    p = ora.softmax_cols(z.astype(np.float64))
+    d = dev.to_device(z); call(dev, "bla_softmax_cols_f32", d, rows, cols)
+    close(d.numpy(), p, rtol=1e-5, scale=1e-6)
+    assert np.abs(d.numpy().sum(0) - 1).max() < 1e-5
+    d = dev.to_device(z); g = dev.empty((rows, cols))
+    call(dev, "bla_softmax_cols_grad_f32", d, rows, cols, dev.to_device(y), 1 / 784, g)
+    close(d.numpy(), p, rtol=1e-5, scale=1e-6)
+    close(g.numpy(), ora.scale(ora.add(p, -y.astype(np.float64)), 1 / 784), rtol=1e-5, scale=1e-8)

@@ -160,15 +160,3 @@ def test_rccl_single_rank_with_torch_buckets(dev):
             assert np.array_equal(a, b)
     finally:
         dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_chain_kernel_variant_gives_the_same_step(mode):
-    """BLA_MNIST_CHAIN=2: the short chain (layer 2, output layer + softmax + loss gradient and dZ2 in one launch, dZ1 a product of its own).
-    BLA_MNIST_CHAIN=1 (read once per process): first layer, then ONE launch for the whole per-sample chain (layer 2, output layer + softmax
-    + loss gradient, dZ2, dZ1 with 16 columns per workgroup), then the three weight gradients as one grouped launch.  Same golden-vector and
-    oracle checks as the default six-launch step: this file's tests, re-run in a process with the switch on."""
-    import os, subprocess, sys
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not chain_kernel_variant"],
-                       env=dict(os.environ, BLA_MNIST_CHAIN=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
