@@ -1092,8 +1092,10 @@ static ParityTaps parity_taps(int k, int pad, int r) {
 	return t;
 }
 // A_class[c][(f, a, b)] = K[f][c][P.tap[a]][Q.tap[b]] for the four classes, back to back in `out`
+struct ClassTable { GatherClass c[4]; };
 __global__ void __launch_bounds__(kThreads) parity_kernels_kernel(const float* __restrict__ kern, float* __restrict__ out, int f_n, int c_n, int k, ParityTaps p0, ParityTaps p1,
-                                                                   ParityTaps q0, ParityTaps q1) {
+                                                                   ParityTaps q0, ParityTaps q1, ClassTable tab, GatherClass* d_tab) {
+	if (d_tab && blockIdx.x == 0 && threadIdx.x < 4) d_tab[threadIdx.x] = tab.c[threadIdx.x];   // the class launch's table (gather_gemm_classes reads it on the device)
 	const int total = f_n * c_n * k * k;
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
 		int cls = 0, base = 0, r = e;
@@ -1186,19 +1188,39 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 	const size_t copy_floats = (size_t)batch * f_n * hh * wh, cls_floats = (size_t)batch * c_in * hc * wc;
 	BLA_REQUIRE(copy_floats < ((size_t)1 << 29) && cls_floats < ((size_t)1 << 29), BLA_ERR_INVALID, "batch too large for 32-bit gather offsets");
 	void* ws;
-	bla_status st = ensure_workspace(slab_bytes + (copy_floats + 4 * cls_floats) * sizeof(float) + 64, &ws);   // [slabs][padded del_y][four class planes]
+	bla_status st = ensure_workspace(slab_bytes + (copy_floats + 4 * cls_floats) * sizeof(float) + 64 + 256, &ws);   // [slabs][padded del_y][four class planes][class table]
 	if (st) return st;
 	float* padded = (float*)((char*)ws + slab_bytes);
 	float* planes = padded + (copy_floats + 3) / 4 * 4;
+	GatherClass* d_tab = (GatherClass*)(((uintptr_t)(planes + 4 * cls_floats) + 63) / 64 * 64);
 	launch_pad_split(s, d_del_y, padded, (unsigned)(batch * f_n), gm.ho, gm.wo, dpmax, dqmax, 1, (unsigned)hh, (unsigned)wh);
-	hipLaunchKernelGGL(parity_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k, P[0], P[1], Q[0], Q[1]);
-	BLA_HIP(hipGetLastError());
 	size_t a_off = 0;
+	GatherClass gc[4];
 	for (int cls = 0; cls < 4; cls++) {
 		const int kc = f_n * P[cls >> 1].n * Q[cls & 1].n;
-		st = gather_gemm(s, 3, batch, c_in, N, kc, d_scratch + a_off, kc, planes + (size_t)cls * cls_floats, hc * wc, padded, t.taps[cls], t.pix, hh, wh, hc * wc, f_n * hh * wh);
-		if (st) return st;
+		gc[cls] = GatherClass{d_scratch + a_off, kc, t.taps[cls], planes + (size_t)cls * cls_floats};
 		a_off += (size_t)c_in * kc;
+	}
+	// one launch for the four classes where they fill the chip: longest contraction beside shortest on a CU (the workgroups are dealt in launch order:
+	// classes sorted [longest, middle, shortest, middle] puts workgroup j and j + half the grid -- the two a CU holds -- on a long and a short one)
+	const bool one_launch = gather_classes_fit(4, c_in, N);
+	ClassTable sorted = {{gc[0], gc[1], gc[2], gc[3]}};
+	if (one_launch) {
+		int order[4] = {0, 1, 2, 3};
+		for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (gc[order[j]].K > gc[order[i]].K) { int x = order[i]; order[i] = order[j]; order[j] = x; }
+		sorted = ClassTable{{gc[order[0]], gc[order[1]], gc[order[3]], gc[order[2]]}};
+	}
+	hipLaunchKernelGGL(parity_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k, P[0], P[1], Q[0], Q[1], sorted,
+	                   one_launch ? d_tab : nullptr);
+	BLA_HIP(hipGetLastError());
+	if (one_launch) {
+		st = gather_gemm_classes(s, batch, c_in, N, sorted.c, d_tab, 4, hc * wc, padded, t.pix, hh, wh, hc * wc, f_n * hh * wh);
+		if (st) return st;
+	} else {
+		for (int cls = 0; cls < 4; cls++) {
+			st = gather_gemm(s, 3, batch, c_in, N, gc[cls].K, gc[cls].A, gc[cls].K, gc[cls].C, hc * wc, padded, gc[cls].ktab, t.pix, hh, wh, hc * wc, f_n * hh * wh);
+			if (st) return st;
+		}
 	}
 	hipLaunchKernelGGL(parity_interleave_kernel, dim3(grid_for((size_t)batch * c_in * h * (w / 2))), dim3(kThreads), 0, s, planes, d_del_x, (unsigned)(batch * c_in), h, w);
 	BLA_HIP(hipGetLastError());

@@ -49,6 +49,31 @@ int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 	return (int)((K + kps - 1) / kps);
 }
 
+// Several forward-shaped products over ONE padded image in one launch (mode 3, half-slab pipeline, whole tiles): the four parity classes of a stride-2
+// data gradient.  blockIdx.y = class.  The classes differ in contraction length (4F, 2F, 2F, F for 3x3 kernels); all 4 x tiles workgroups are resident
+// at once (two per CU), so the ORDER decides which classes share a CU: longest with shortest, the two middle ones together (cls[] as given: the
+// caller sorts).  Needs about two workgroups per CU in total; otherwise the caller runs the classes one by one with their taps cut over workgroups.
+bool gather_classes_fit(int ncls, int M, int N) {
+	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
+	return ncls >= 2 && ncls <= 4 && gather_hs(3, M, N) && (long)ncls * (M / 128) * (N / 128) >= 2L * cus - cus / 2;
+}
+bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const GatherClass* cls, const GatherClass* d_cls, int ncls, int ldc, const float* img,
+                               const int2* ntab, int H, int W, int HWo, int img_stride) {
+	BLA_REQUIRE(gather_classes_fit(ncls, M, N) && N % 4 == 0 && HWo % 4 == 0 && (long)batch * img_stride < (1L << 29), BLA_ERR_INVALID, "class launch: M=%d N=%d classes=%d", M, N, ncls);
+	GemmArgs a = {};
+	a.M = M; a.N = N; a.ldc = ldc; a.alpha = 1.f; a.act = BLA_ACT_NONE;
+	a.g_img = img; a.g_zero = zero_word(); a.g_ntab = ntab; a.g_mode = 3; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
+	a.tiles_m = M / 128; a.tiles_n = N / 128; a.splits = 1; a.k_per_split = 1 << 30;
+	a.g_ncls = ncls; a.g_cls = d_cls;       // d_cls: the same entries in device memory (the caller's launch wrote them)
+	for (int i = 0; i < ncls; i++)
+		BLA_REQUIRE(cls[i].K > 0 && cls[i].K % 16 == 0 && (uintptr_t)cls[i].A % 16 == 0, BLA_ERR_INVALID, "class %d: K = %d", i, cls[i].K);
+	a.A = cls[0].A; a.C = cls[0].C; a.g_ktab = cls[0].ktab; a.K = cls[0].K; a.lda = a.K;
+	const dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)ncls, 1), block(256);
+	hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, 2 * (128 + 128) * 16 * sizeof(float), s, a);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
+}
+
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
                        const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep) {
 	BLA_REQUIRE((mode >= 1 && mode <= 4) || mode == 7, BLA_ERR_INVALID, "gather mode %d", mode);

@@ -51,6 +51,11 @@ struct GemmArgs {
 	const float* g_bias; int g_bias_stride; const float* g_add; float* g_out2;
 	int rc_global;   // host-side only: pick the instantiation that fetches row-contiguous operands with global_load_lds
 	int wsk_tile;    // wave-split-K kernels: 32 (32x32 tiles, MFMA 32x32x2) or 16 (16x16 tiles, MFMA 16x16x4)
+	// mode 3, several products over the SAME gathered image in one launch (the parity classes of a stride-2 data gradient, bla_conv.hip): blockIdx.y =
+	// product; each brings its own kernels, contraction length, tap table and output plane; M, N, the image and the pixel table are shared
+	// (the table lives in DEVICE memory: arrays inside this by-value block, indexed by blockIdx.y, made hipcc copy the whole block to scratch)
+	int g_ncls;
+	const GatherClass* g_cls;
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int r, int c, float acc) {
@@ -137,6 +142,10 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	const int wk = wave / (WM * WN), wsp = wave % (WM * WN);   // group along K, position in the tile
 	const int wm0 = (wsp / WN) * (BM / WM), wn0 = (wsp % WN) * (BN / WN);
 
+	if (GATHER == 3 && HS && p.g_ncls > 1) {
+		const GatherClass c = p.g_cls[blockIdx.y];
+		p.A = c.A; p.C = c.C; p.g_ktab = c.ktab; p.K = c.K; p.lda = c.K;
+	}
 	// virtual block id -> tile origin: XCD remap, then groups of 8 tile-rows walked column by column
 	auto tile_origin = [&](int vb, int& tm0, int& tn0) {
 		int pid = xcd_remap(vb, p.tiles_m * p.tiles_n);

@@ -48,6 +48,11 @@ struct GatherEpilogue { const float* bias; int bias_stride; const float* add; fl
 bool gather3_fuses_epilogue(int M, int N, int K);                      // true: gather_gemm(mode 3, ...) takes a GatherEpilogue
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
                        const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep = nullptr);
+// mode 3, up to four products over the same padded image in one launch (bla_gather.hip): each class its kernels A [M][K] (lda = K), tap table and output
+struct GatherClass { const float* A; int K; const int2* ktab; float* C; };
+bool gather_classes_fit(int ncls, int M, int N);
+bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const GatherClass* cls, const GatherClass* d_cls, int ncls, int ldc, const float* img,
+                               const int2* ntab, int H, int W, int HWo, int img_stride);
 
 // bla_conv.hip: implicit-GEMM convolution with the adds the U-Net puts behind it: out = conv + ep_bias[image * ep_bias_stride + channel];
 // ep_out2 = out + ep_add, both optional.  One image: folded into the store; a batch: one pass behind the product.
