@@ -347,7 +347,7 @@ def test_headline_shapes_batch_64_against_the_oracle(dev, ora, shape):
                                    (128, 4, 8, 128, 128, 3, 1),      # rows of two chunks: every chunk is a row end
                                    (8, 32, 32, 256, 128, 3, 1)])     # concatenated inputs (256 -> 128, the up-sampling blocks' first convolution) on 64 tiles
 def test_tiled_gather_straight_from_the_image(dev, ora, shape):
-    """Stride-1 convolutions whose whole 128-wide tiles run WITHOUT a padded copy (gather modes 5 / 6: tap-major contraction, rows outside the image from a
-    zero word, the element beyond a row's end patched in LDS): the geometries that stress exactly that -- 1x1 and even kernels, tiles that straddle
-    images, maps whose rows are one or two 16-byte chunks -- against the oracle like the shapes above (same checks, same tolerances)."""
+    """Stride-1 geometries that stress the tiled gather paths' edge handling -- 1x1 and even kernels, tiles that straddle images, maps whose rows are one
+    or two 16-byte chunks -- against the oracle like the shapes above (same checks, same tolerances).  (Written for the unpadded tap-major kernels of
+    commit 77757e6, which were correct on all of them and slower than the padded copy; the shapes now run the padded / window / checked paths.)"""
     test_batched_conv_tiled_gather_kernel(dev, ora, shape)
