@@ -1053,6 +1053,8 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	BLA_REQUIRE(d_x && d_kern && d_out, BLA_ERR_INVALID, "null operand");
 	hipStream_t s = pick_stream(stream);
 	Geometry gm = same_geometry(h, w, k, stride);
+	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
+	if (thin_conv_applies(k, c_in, f_n, stride)) return thin_conv_forward(s, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, gm.pt, gm.pl, ep_bias, ep_bias_stride, ep_add, ep_out2);
 	ConvArgs a;
 	a.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
 	st = get_table(s, a.g, &a.tab);
@@ -1060,7 +1062,6 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	a.A = d_kern; a.lda = k * k * c_in; a.img = d_x; a.out = d_out; a.ldo = gm.ho * gm.wo;
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
 	const bool ep = ep_bias || ep_out2;
-	BLA_REQUIRE((ep_add == nullptr) == (ep_out2 == nullptr), BLA_ERR_INVALID, "ep_add and ep_out2 go together");
 	const FwdPlan plan = plan_forward(a, batch);
 	if (ep && !plan.fuses_epilogue) {
 		// the half-slab forward kernels apply the adds where they store their tiles (one pass over K, whole tiles) and the 32x32 kernel does for a single
@@ -1236,6 +1237,21 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 	hipStream_t s = pick_stream(stream);
 	Geometry gm = same_geometry(h, w, k, stride);
 	const size_t x_sz = (size_t)c_in * h * w, y_sz = (size_t)f_n * gm.ho * gm.wo;
+	if (thin_conv_applies(k, c_in, f_n, stride)) {
+		// a side of at most four channels: direct kernels (bla_conv_thin.hip); the data gradient is the forward form on del_y with the flipped kernels
+		if (d_del_kern) {
+			BLA_REQUIRE(d_x, BLA_ERR_INVALID, "weight gradient needs the forward input");
+			st = thin_conv_wgrad(s, d_del_y, d_x, d_del_kern, batch, h, w, k, c_in, f_n, gm.pt, gm.pl);
+			if (st) return st;
+		}
+		if (d_del_x) {
+			BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
+			hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+			BLA_HIP(hipGetLastError());
+			return thin_conv_forward(s, d_del_y, d_scratch, d_del_x, batch, h, w, k, f_n, c_in, k - 1 - gm.pt, k - 1 - gm.pl, nullptr, 0, nullptr, nullptr);
+		}
+		return BLA_OK;
+	}
 	if (d_del_kern && d_del_x && stride == 1) {
 		// both gradients, both on the latency-bound kernel: one gather launch and one fold launch for the two
 		BLA_REQUIRE(d_x && d_kern && d_scratch, BLA_ERR_INVALID, "the gradients need the forward input, the kernels and a scratch buffer of F*C*k*k floats");

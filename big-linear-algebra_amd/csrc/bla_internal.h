@@ -59,6 +59,12 @@ bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const Gat
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
                                    const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0);
 
+// bla_conv_thin.hip: direct convolutions for at most four channels on one side (stride 1, k 1 or 3): forward with the optional epilogue, weight gradient
+bool thin_conv_applies(int k, int c_in, int f_n, int stride);
+bla_status thin_conv_forward(hipStream_t s, const float* x, const float* kern, float* out, int batch, int h, int w, int k, int c_in, int f_n, int pt, int pl,
+                             const float* ep_bias, int ep_bias_stride, const float* ep_add, float* ep_out2);
+bla_status thin_conv_wgrad(hipStream_t s, const float* del_y, const float* x, float* del_kern, int batch, int h, int w, int k, int c_in, int f_n, int pt, int pl);
+
 // group norm + ReLU + dropout in one pass (relu = max(norm, 0), dropped = drop ? 0 : relu), model/cifar_unet.c:1056-1058
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
                                    int channels, int group_size, int hw);

@@ -298,6 +298,24 @@ def test_batched_conv_tiled_gather_kernel(dev, ora, shape):
     assert (np.abs(dkern.numpy() - want_dk) <= 1e-5 * bound_dk + 1e-30).all(), shape
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 32, 3, 128, 3, 1), (64, 32, 32, 3, 128, 1, 1),     # the U-Net's first block: 3 -> 128, k 3 and the 1x1 residual (:1102)
+                                   (64, 32, 32, 128, 3, 3, 1),                                  # its output convolution: 128 -> 3 (:1165)
+                                   (5, 16, 12, 3, 40, 3, 1), (3, 10, 10, 50, 4, 1, 1), (2, 8, 8, 130, 2, 3, 1), (3, 16, 16, 4, 4, 3, 1), (1, 7, 9, 1, 33, 3, 1)])
+def test_thin_convolutions(dev, ora, shape):
+    """At most four channels on one side (csrc/bla_conv_thin.hip: direct kernels on the vector ALUs, no MFMA tile fits a 3-wide side): forward,
+    data gradient (the few-inputs form on del_y with the flipped kernels, and the reverse) and the weight gradient folded over the batch in a fixed
+    order, against the oracle like every other batched shape; ragged pixel blocks, channel counts that are no multiple of the quarters / groups."""
+    test_batched_conv_tiled_gather_kernel(dev, ora, shape)
+    batch, h, w, cin, cout, k, s = shape
+    x = uniform(820, (batch, cin, h, w), -1, 1, F32); kern = uniform(821, (cout, cin, k, k), -0.3, 0.3, F32)
+    outs = []
+    for _ in range(2):                      # deterministic: two runs, the same bits
+        out = dev.empty((batch, cout, h, w)).fill_bytes(0xFF)
+        call(dev, "bla_conv2d_forward_batched_f32", dev.to_device(x), dev.to_device(kern), out, batch, h, w, k, cin, cout, s)
+        outs.append(out.numpy())
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("shape", [(64, 32, 32, 128, 128, 3, 1),     # SURVEY 8(d) cfg 5 headline: (M,K,N) = (1024,1152,128) per image -- what bench.py's tertiary line times
                                    (64, 16, 16, 256, 256, 3, 1),     # the second headline shape: (256,2304,256)
                                    (64, 32, 32, 128, 256, 3, 2)])    # the U-Net's first down-convolution (model/cifar_unet.c:1105): stride 2, data gradient by output parity
