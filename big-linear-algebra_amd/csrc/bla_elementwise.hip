@@ -564,34 +564,37 @@ __global__ void __launch_bounds__(T) softmax_row_block_kernel(float* __restrict_
 
 // per row (lib/util.c:36-55): one wave per row.  Rows of up to 64*32 = 2048 elements are held in registers
 // (one read + one write per element); longer rows take the three-pass route of the reference.
+template <int NI>   // rows of up to 64 * NI elements stay in registers
+__device__ __forceinline__ void softmax_row_in_registers(float* __restrict__ row, int cols, int lane) {
+	float v[NI];
+	float mx = -INFINITY;
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		int j = lane + 64 * i;
+		v[i] = j < cols ? row[j] : -INFINITY;
+		mx = fmaxf(mx, v[i]);
+	}
+	mx = __shfl(wave_max(mx), 0, 64);
+	double s = 0;
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		v[i] = lane + 64 * i < cols ? expf(v[i] - mx) : 0.f;
+		s += v[i];
+	}
+	float sf = (float)__shfl(wave_sum(s), 0, 64);
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		int j = lane + 64 * i;
+		if (j < cols) row[j] = v[i] / sf;
+	}
+}
 __global__ void __launch_bounds__(kThreads) softmax_rows_kernel(float* __restrict__ d, int rows, int cols) {
 	int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (r >= rows) return;
 	float* row = d + (size_t)r * cols;
-	if (cols <= 2048) {
-		float v[32];
-		float mx = -INFINITY;
-#pragma unroll
-		for (int i = 0; i < 32; i++) {
-			int j = lane + 64 * i;
-			v[i] = j < cols ? row[j] : -INFINITY;
-			mx = fmaxf(mx, v[i]);
-		}
-		mx = __shfl(wave_max(mx), 0, 64);
-		double s = 0;
-#pragma unroll
-		for (int i = 0; i < 32; i++) {
-			v[i] = lane + 64 * i < cols ? expf(v[i] - mx) : 0.f;
-			s += v[i];
-		}
-		float sf = (float)__shfl(wave_sum(s), 0, 64);
-#pragma unroll
-		for (int i = 0; i < 32; i++) {
-			int j = lane + 64 * i;
-			if (j < cols) row[j] = v[i] / sf;
-		}
-		return;
-	}
+	if (cols <= 256) { softmax_row_in_registers<4>(row, cols, lane); return; }     // the attention block's 256-token rows: no work on dead slots
+	if (cols <= 512) { softmax_row_in_registers<8>(row, cols, lane); return; }
+	if (cols <= 2048) { softmax_row_in_registers<32>(row, cols, lane); return; }
 	float mx = -INFINITY;
 	for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, row[j]);
 	mx = wave_max(mx);

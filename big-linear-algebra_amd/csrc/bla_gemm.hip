@@ -970,6 +970,15 @@ bla_status bla_gemm_batched_f32(void* stream, int transa, int transb, int m, int
 	BLA_REQUIRE(batch >= 1, BLA_ERR_INVALID, "batch %d", batch);
 	BLA_REQUIRE(!ep || (!ep->relu_mask && !ep->row_sum_a && !ep->softmax_grad), BLA_ERR_INVALID, "batched products take alpha / beta, the biases, act and pre_act only");
 	if (batch == 1) return gemm_impl(stream, transa, transb, m, n, k, A, lda, B, ldb, C, ldc, ep, nullptr);
+	if (g_force_config < 0 && g_force_split <= 0 && gemm_thin_applies(m, n, k, batch) && (!ep || (!ep->bias_col && ep->act == BLA_ACT_NONE))) {
+		// short contraction, large output (the attention block's S x S products): HBM-bound, one wave per output block (bla_gemm_thin.hip)
+		BLA_REQUIRE(A && B && C, BLA_ERR_INVALID, "null operand");
+		const ThinPart part = {A, B, stride_a, stride_b, lda, ldb};
+		bla_status st = gemm_thin_parts(stream, transa, transb, m, n, k, &part, 1, C, ldc, stride_c, batch, ep ? ep->alpha : 1.f, ep ? ep->beta : 0.f,
+		                                ep ? ep->bias_row : nullptr, ep ? ep->pre_act : nullptr, ep ? ep->ld_pre : 0, stride_pre);
+		if (st == BLA_OK) snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_thin_%c%c_x%d", transa ? 't' : 'n', transb ? 't' : 'n', batch);
+		return st;
+	}
 	WskPlan pl = {};
 	const bool aligned = stride_a % 4 == 0 && stride_b % 4 == 0 && stride_c % 4 == 0 && stride_pre % 4 == 0;
 	t_plan_batch = batch;

@@ -65,6 +65,13 @@ bla_status thin_conv_forward(hipStream_t s, const float* x, const float* kern, f
                              const float* ep_bias, int ep_bias_stride, const float* ep_add, float* ep_out2);
 bla_status thin_conv_wgrad(hipStream_t s, const float* del_y, const float* x, float* del_kern, int batch, int h, int w, int k, int c_in, int f_n, int pt, int pl);
 
+// bla_gemm_thin.hip: batched products with a short contraction (k <= 64, a multiple of 8; m, n multiples of 32) and a large output, one wave per
+// 32 x (32..128) block straight from global memory; up to three (A, B) pairs accumulate before the one store.  Strides in floats per batch index.
+struct ThinPart { const float* A; const float* B; long sa, sb; int lda, ldb; };
+bool gemm_thin_applies(int m, int n, int k, int batch);
+bla_status gemm_thin_parts(void* stream, int transa, int transb, int m, int n, int k, const ThinPart* parts, int nparts, float* C, int ldc, long stride_c, int batch,
+                           float alpha, float beta, const float* bias_row, float* pre, int ld_pre, long stride_pre);
+
 // group norm + ReLU + dropout in one pass (relu = max(norm, 0), dropped = drop ? 0 : relu), model/cifar_unet.c:1056-1058
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
                                    int channels, int group_size, int hw);

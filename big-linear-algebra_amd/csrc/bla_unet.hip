@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kT) sum_kernel(float* __restrict__ out, const 
 }
 
 // _softmax_ddx, model/cifar_unet.c:1246-1259: one wave per row; out = s * (g - <s, g>)
-__global__ void __launch_bounds__(kT) softmax_ddx_kernel(const float* __restrict__ s, const float* __restrict__ g, float* __restrict__ out, int rows, int dim) {
+__global__ void __launch_bounds__(kT) softmax_ddx_kernel(const float* __restrict__ s, const float* __restrict__ g, float* __restrict__ out, int rows, int dim, float scale) {
 	int r = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (r >= rows) return;
 	const float* sr = s + (size_t)r * dim; const float* gr = g + (size_t)r * dim;
@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(kT) softmax_ddx_kernel(const float* __restrict
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
 	float d = (float)__shfl(dot, 0, 64);
-	for (int j = lane; j < dim; j += 64) out[(size_t)r * dim + j] = sr[j] * (gr[j] - d);
+	if (scale == 1.f) { for (int j = lane; j < dim; j += 64) out[(size_t)r * dim + j] = sr[j] * (gr[j] - d); }
+	else { for (int j = lane; j < dim; j += 64) out[(size_t)r * dim + j] = (sr[j] * (gr[j] - d)) * scale; }   // the matrix_scale behind it (:1308), same rounding
 }
 // dst[i] = sum over the images of src[b][i] (in image order): weight gradients of a batch from per-image products
 __global__ void __launch_bounds__(kT) batch_sum_kernel(const float* __restrict__ src, float* __restrict__ dst, int batch, size_t n) {
@@ -161,7 +162,7 @@ bla_status bla_softmax_ddx_f32(void* stream, const float* d_softmax_output, cons
 	BLA_REQUIRE(rows >= 0 && dim >= 0, BLA_ERR_INVALID, "bad shape %dx%d", rows, dim);
 	if (rows == 0 || dim == 0) return BLA_OK;
 	BLA_REQUIRE(d_softmax_output && d_gradient && d_out, BLA_ERR_INVALID, "null operand");
-	hipLaunchKernelGGL(softmax_ddx_kernel, dim3((rows + 3) / 4), dim3(kT), 0, pick_stream(stream), d_softmax_output, d_gradient, d_out, rows, dim);
+	hipLaunchKernelGGL(softmax_ddx_kernel, dim3((rows + 3) / 4), dim3(kT), 0, pick_stream(stream), d_softmax_output, d_gradient, d_out, rows, dim, 1.f);
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
 }
@@ -279,8 +280,9 @@ bla_status bla_attention_backward_batched_f32(void* stream, int batch, const flo
 	st = bgemm(stream, 1, 1, s, d, c, d_del_y, s, xs, d_w, c, 0, del_p, d, qs, batch); if (st) return st;                       // del_P = del_Y' W^T       :1295-1297
 	st = bgemm(stream, 0, 1, s, s, d, del_p, d, qs, fw->v, d, qs, del_s, s, ss, batch); if (st) return st;                      // del_S = del_P V^T        :1303-1305
 	st = bgemm(stream, 1, 0, s, d, s, fw->weights, s, ss, del_p, d, qs, del_v, d, qs, batch); if (st) return st;                // del_V = S^T del_P        :1299-1301
-	st = bla_softmax_ddx_f32(stream, jacobian_from_raw ? fw->scores_raw : fw->weights, del_s, del_i, batch * s, s); if (st) return st;   // :1307
-	st = bla_scale_f32(stream, del_i, (size_t)batch * s * s, inv); if (st) return st;                                         // :1308
+	hipLaunchKernelGGL(softmax_ddx_kernel, dim3((batch * s + 3) / 4), dim3(kT), 0, pick_stream(stream), jacobian_from_raw ? fw->scores_raw : fw->weights, del_s, del_i,
+	                   batch * s, s, inv);                                                                                    // :1307-1308 in one pass
+	BLA_HIP(hipGetLastError());
 	st = bgemm(stream, 0, 0, s, d, s, del_i, s, ss, fw->k, d, qs, del_q, d, qs, batch); if (st) return st;                      // :1310
 	st = bgemm(stream, 1, 0, s, d, s, del_i, s, ss, fw->q, d, qs, del_k, d, qs, batch); if (st) return st;                      // :1312-1314
 	st = bgemm(stream, 0, 0, c, d, s, d_x, s, xs, del_k, d, qs, d_partials, d, ws_, batch); if (st) return st;                  // Z^T = X                :1316-1319
@@ -289,6 +291,10 @@ bla_status bla_attention_backward_batched_f32(void* stream, int batch, const flo
 	st = batch_sum(stream, d_partials, d_del_wq, batch, (size_t)ws_); if (st) return st;
 	st = bgemm(stream, 0, 0, c, d, s, d_x, s, xs, del_v, d, qs, d_partials, d, ws_, batch); if (st) return st;
 	st = batch_sum(stream, d_partials, d_del_wv, batch, (size_t)ws_); if (st) return st;
+	if (gemm_thin_applies(c, s, d, batch)) {   // the three d-deep terms of del_Z^T accumulate in registers (q, then k, then v) and are stored once  :1322-1334
+		const ThinPart parts[3] = {{d_wq, del_q, 0, qs, d, d}, {d_wk, del_k, 0, qs, d, d}, {d_wv, del_v, 0, qs, d, d}};
+		return gemm_thin_parts(stream, 0, 1, c, s, d, parts, 3, d_del_x, s, xs, batch, 1.f, 0.f, nullptr, nullptr, 0, 0);
+	}
 	st = bgemm(stream, 0, 1, c, s, d, d_wq, d, 0, del_q, d, qs, d_del_x, s, xs, batch); if (st) return st;                      // del_Z^T, same add order :1322-1334
 	st = bgemm(stream, 0, 1, c, s, d, d_wk, d, 0, del_k, d, qs, d_del_x, s, xs, batch, 1.f, 1.f); if (st) return st;
 	return bgemm(stream, 0, 1, c, s, d, d_wv, d, 0, del_v, d, qs, d_del_x, s, xs, batch, 1.f, 1.f);

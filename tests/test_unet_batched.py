@@ -44,6 +44,33 @@ def test_batched_gemm(dev, ta, tb):
         close(c.numpy(), want, 2e-6 * np.sqrt(k), (j, "c")); close(pre.numpy(), want, 2e-6 * np.sqrt(k), (j, "pre"))
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_batched_gemm_short_contraction(dev, ta, tb):
+    """k <= 64 with a large output (csrc/bla_gemm_thin.hip: one wave per 32 x 32..128 output block, fragments straight from global memory): the
+    attention block's S x S shapes at batch 64, ragged wave jobs, every k class, leading dimensions that rule out 16-byte loads, a shared
+    operand (stride 0), alpha / beta / bias_row / pre_act together.  Against float64 products."""
+    L = dev.lib(); chk = dev.native.check
+    for j, (batch, m, n, k, pad, share_b) in enumerate([(64, 256, 256, 16, 0, False), (64, 256, 256, 16, 0, True), (80, 96, 160, 24, 1, False), (40, 32, 1024, 64, 0, False),
+                                                        (130, 64, 128, 8, 3, True), (20, 288, 224, 40, 2, False)]):
+        am, ak = (k, m) if ta else (m, k)
+        bk, bn = (n, k) if tb else (k, n)
+        a = uniform(500 + j, (batch, am, ak + pad), -1, 1, F32); b = uniform(600 + j, ((1 if share_b else batch), bk, bn + pad), -1, 1, F32)
+        c0 = uniform(700 + j, (batch, m, n), -1, 1, F32); bias = uniform(800 + j, (m,), -1, 1, F32)
+        da, db, dbias = dev.to_device(a), dev.to_device(b), dev.to_device(bias)
+        c = dev.to_device(c0); pre = dev.empty((batch, m, n)).fill_bytes(0xFF)
+        ep = dev.native.Epilogue(); ep.alpha = 0.25; ep.beta = -0.5; ep.bias_row = dbias.ptr; ep.pre_act = pre.ptr; ep.ld_pre = n
+        chk(L.bla_gemm_batched_f32(None, ta, tb, m, n, k, da.ptr, ak + pad, am * (ak + pad), db.ptr, bn + pad, 0 if share_b else bk * (bn + pad), c.ptr, n, m * n, batch,
+                                   C.byref(ep), m * n))
+        assert dev.lib().bla_gemm_last_kernel().decode().startswith("gemm_f32_thin"), dev.lib().bla_gemm_last_kernel().decode()
+        A = a[:, :, :ak].astype(np.float64); B = b[:, :, :bn].astype(np.float64)
+        A = A.transpose(0, 2, 1) if ta else A
+        B = B.transpose(0, 2, 1) if tb else B
+        raw = 0.25 * (A @ B) + bias.astype(np.float64)[None, :, None]
+        bound = 0.25 * (np.abs(A) @ np.abs(B)) + 1.0
+        assert (np.abs(pre.numpy() - raw) <= 1e-5 * bound).all(), (j, "pre")
+        assert (np.abs(c.numpy() - (raw - 0.5 * c0)) <= 1e-5 * bound).all(), (j, "c")
+
+
 def resnet_case(pkg, batch, cin, cout, hh, tdim, gs, seed):
     N = pkg.native
     hw = hh * hh; g1 = (cin + gs - 1) // gs; g2 = (cout + gs - 1) // gs
