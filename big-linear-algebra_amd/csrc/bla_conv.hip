@@ -378,6 +378,9 @@ struct ConvArgs {
 	float* ep_out2 = nullptr;
 	int ep_bias_stride = 0;      // batched tiled forward only: bias set per image
 	bool ep_fused_tiled = false; // the tiled (padded-copy, half-slab) forward kernel applies the epilogue itself
+	// data gradient on the window kernel: A is still to be made -- the forward kernels [F][C][3][3] (F = this product's K / 9, C = its M), flipped and
+	// re-ordered in one pass (window_order_flipped_kernel) instead of flip_kernels_kernel + window_order_kernels_kernel
+	const float* flip_src = nullptr;
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -726,6 +729,14 @@ __global__ void __launch_bounds__(kThreads) window_order_kernels_kernel(const fl
 		out[e] = a[(size_t)m * kdim + (g * 16 + c16) * 9 + t];
 	}
 }
+// the same for the data gradient, straight from the forward kernels kern[f][m][3][3]: row m, contraction (g, t, f16) <- kern[16 g + f16][m][8 - t]
+__global__ void __launch_bounds__(kThreads) window_order_flipped_kernel(const float* __restrict__ kern, float* __restrict__ out, int rows, int f_n) {
+	const int kdim = f_n * 9, total = rows * kdim;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+		const int m = e / kdim, r = e - m * kdim, g = r / 144, q = r - g * 144, t = q >> 4, f16 = q & 15;
+		out[e] = kern[((size_t)(g * 16 + f16) * rows + m) * 9 + 8 - t];
+	}
+}
 struct FwdPlan { FwdPath path; bool fuses_epilogue; };
 static FwdPlan plan_forward(const ConvArgs& a, int batch) {
 	if (!use_tiled_gather(a, batch, 1)) return FwdPlan{FWD_WSK, batch == 1};   // (the 32x32 kernel applies one bias set where it stores: a single image)
@@ -773,7 +784,8 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 		void* ws;
 		bla_status st = ensure_workspace((size_t)a.M * a.K * sizeof(float) + 64, &ws);
 		if (st) return st;
-		hipLaunchKernelGGL(window_order_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, (float*)ws, a.M, a.g.c);
+		if (a.flip_src) hipLaunchKernelGGL(window_order_flipped_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.flip_src, (float*)ws, a.M, a.g.c);
+		else hipLaunchKernelGGL(window_order_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, (float*)ws, a.M, a.g.c);
 		BLA_HIP(hipGetLastError());
 		const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
 		return gather_gemm(s, 7, batch, a.M, a.N * batch, a.K, (const float*)ws, a.K, a.out, a.ldo, a.img, nullptr, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
@@ -1292,9 +1304,6 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		}
 		BLA_REQUIRE(d_kern && d_scratch, BLA_ERR_INVALID, "data gradient needs the kernels and a scratch buffer of F*C*k*k floats");
 		if (parity_dgrad_applies(batch, h, w, k, c_in, f_n, stride, gm)) return conv2d_backward_parity(s, d_del_y, d_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, gm);
-		int total = f_n * c_in * k * k;
-		hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)total)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
-		BLA_HIP(hipGetLastError());
 		// Stride s > 1 (the intended adjoint; the reference is undefined there): the same stride-1 convolution over del_y with s-1 zeros
 		// put between its pixels, [F][(Ho-1)s+1][(Wo-1)s+1] -- the U-Net's three down-convolutions (model/cifar_unet.c:1105,1111,1115).
 		const float* src = d_del_y;
@@ -1316,6 +1325,11 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
+		if (plan_forward(a, batch).path == FWD_TILED_WINDOW) a.flip_src = d_kern;      // flipped and window-ordered in one pass, inside launch_implicit
+		else {
+			hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+			BLA_HIP(hipGetLastError());
+		}
 		st = launch_implicit<CONV_FWD>(s, a, batch, src_sz, x_sz, 0);
 		if (st) return st;
 	}

@@ -41,7 +41,26 @@ int gather3_splits(int M, int N, int K) {
 	const long per = (slabs + splits - 1) / splits;
 	return (int)((slabs + per - 1) / per);
 }
-bool gather3_fuses_epilogue(int M, int N, int K) { return gather_hs(3, M, N) && gather3_splits(M, N, K) == 1; }
+// one pass over K: where the tile is stored; taps cut over workgroups (small maps): in the fold of the slabs (gather_fold_epilogue_kernel)
+bool gather3_fuses_epilogue(int M, int N, int K) { (void)K; return gather_hs(3, M, N); }
+
+// The fold of a mode-3 product whose taps were cut over workgroups, with the adds the U-Net puts behind the convolution: slabs [split][image][M][HWo]
+// summed in split order, + bias[image * stride + row], second output = that + add.  16 bytes per thread.
+__global__ void __launch_bounds__(256) gather_fold_epilogue_kernel(const float4* __restrict__ slab, float4* __restrict__ out, int splits, size_t total4, const float* __restrict__ bias,
+                                                                    int bias_stride, const float4* __restrict__ add, float4* __restrict__ out2, int M, int hwo4) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+		float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+		for (int z = 0; z < splits; z++) { const float4 v = slab[(size_t)z * total4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+		if (bias) {
+			const size_t row = i / hwo4;
+			const int image = (int)(row / M), ch = (int)(row - (size_t)image * M);
+			const float b = bias[(size_t)image * bias_stride + ch];
+			s.x += b; s.y += b; s.z += b; s.w += b;
+		}
+		out[i] = s;
+		if (out2) { const float4 a = add[i]; out2[i] = make_float4(s.x + a.x, s.y + a.y, s.z + a.z, s.w + a.w); }
+	}
+}
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 	if (mode != 2 && mode != 4) return 1;
 	const long K = (long)batch * HWo;
@@ -121,9 +140,10 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
 	// whole tiles: the half-slab pipeline (fragment sets per k-half, every LDS read and DMA dealt out between MFMAs) -- BLA_CONV_HS=0 keeps the older form
 	const bool hs = gather_hs(mode, M, N);
-	if (ep && (ep->bias || ep->out2)) {
-		BLA_REQUIRE(mode == 3 && hs && splits == 1, BLA_ERR_INVALID, "the fused convolution epilogue needs the half-slab forward kernel in one pass over K (gather3_fuses_epilogue)");
-		a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2;
+	const bool with_ep = ep && (ep->bias || ep->out2);
+	if (with_ep) {
+		BLA_REQUIRE(mode == 3 && hs, BLA_ERR_INVALID, "the fused convolution epilogue needs the half-slab forward kernel (gather3_fuses_epilogue)");
+		if (splits == 1) { a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2; }
 	}
 	if (hs && mode == 3) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 3, false, true>), grid, block, lds_bytes, s, a);
 	else if (hs) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true>), grid, block, lds_bytes, s, a);
@@ -136,6 +156,15 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 		GemmArgs r = a;
 		if (mode == 4) { r.M = N; r.N = M; }   // the slabs hold the transposed tile: [split][N][M] -> C [N][M]
 		if (mode == 3) r.ldc = r.N;            // C-shaped slabs ([image][M][HWo]): a flat sum
+		if (with_ep) {
+			const size_t total4 = (size_t)M * N / 4;
+			BLA_REQUIRE((uintptr_t)C % 16 == 0 && (!ep->out2 || ((uintptr_t)ep->out2 % 16 == 0 && (uintptr_t)ep->add % 16 == 0)), BLA_ERR_INVALID, "unaligned convolution output");
+			const size_t blocks = (total4 + 255) / 256;
+			hipLaunchKernelGGL(gather_fold_epilogue_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, (const float4*)a.slab, (float4*)C, splits, total4,
+			                   ep->bias, ep->bias_stride, (const float4*)ep->add, (float4*)ep->out2, M, HWo / 4);
+			BLA_HIP(hipGetLastError());
+			return BLA_OK;
+		}
 		BLA_HIP(launch_splitk_reduce(r, s));
 	}
 	return BLA_OK;

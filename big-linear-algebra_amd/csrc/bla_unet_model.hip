@@ -144,6 +144,20 @@ __global__ void __launch_bounds__(256) unet_concat_kernel(const float* __restric
 		cat[e] = r < n ? a[b * n + r] : skip[b * n + r - n];
 	}
 }
+// the same 16 bytes at a time (n a multiple of 4)
+__global__ void __launch_bounds__(256) unet_concat4_kernel(const float4* __restrict__ a, const float4* __restrict__ skip, float4* __restrict__ cat, size_t n4, size_t total4) {
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = e / (2 * n4), r = e - b * 2 * n4;
+		cat[e] = r < n4 ? a[b * n4 + r] : skip[b * n4 + r - n4];
+	}
+}
+__global__ void __launch_bounds__(256) unet_split4_kernel(const float4* __restrict__ g_cat, float4* __restrict__ g_main, float4* __restrict__ g_skip, size_t n4, size_t total4) {
+	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = e / (2 * n4), r = e - b * 2 * n4;
+		const float4 v = g_cat[e];
+		if (r < n4) g_main[b * n4 + r] = v; else g_skip[b * n4 + r - n4] = v;
+	}
+}
 // _split_concat, :1339-1349, per image: the first half is the main path's gradient, the second the skip connection's
 __global__ void __launch_bounds__(256) unet_split_kernel(const float* __restrict__ g_cat, float* __restrict__ g_main, float* __restrict__ g_skip, size_t n, size_t total) {
 	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -315,7 +329,9 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 		return bla_conv2d_forward_batched_f32(stream, in, P + k.kern, k.out, B, k.h, k.w, k.k, k.cin, k.cout, k.stride);
 	};
 	auto concat = [&](int stage, const float* a, const float* skip, size_t n) -> bla_status {   // _concat_skip, :1088-1097 (n: floats per image and half)
-		hipLaunchKernelGGL(unet_concat_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, a, skip, m->cat[stage], n, 2 * n * B);
+		if (n % 4 == 0 && ((uintptr_t)a | (uintptr_t)skip | (uintptr_t)m->cat[stage]) % 16 == 0)
+			hipLaunchKernelGGL(unet_concat4_kernel, dim3(grid_of(n / 2 * B)), dim3(256), 0, s, (const float4*)a, (const float4*)skip, (float4*)m->cat[stage], n / 4, n / 2 * B);
+		else hipLaunchKernelGGL(unet_concat_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, a, skip, m->cat[stage], n, 2 * n * B);
 		BLA_HIP(hipGetLastError());
 		return BLA_OK;
 	};
@@ -394,7 +410,9 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 	};
 	// _split_concat, :1339-1349: the first half of a concatenation's gradient goes on along the main path, the second is the skip connection's
 	auto split = [&](int stage, const float* g_cat, float* g_main, size_t n) -> bla_status {
-		hipLaunchKernelGGL(unet_split_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, g_cat, g_main, m->gskip[stage], n, 2 * n * B);
+		if (n % 4 == 0 && ((uintptr_t)g_cat | (uintptr_t)g_main | (uintptr_t)m->gskip[stage]) % 16 == 0)
+			hipLaunchKernelGGL(unet_split4_kernel, dim3(grid_of(n / 2 * B)), dim3(256), 0, s, (const float4*)g_cat, (float4*)g_main, (float4*)m->gskip[stage], n / 4, n / 2 * B);
+		else hipLaunchKernelGGL(unet_split_kernel, dim3(grid_of(2 * n * B)), dim3(256), 0, s, g_cat, g_main, m->gskip[stage], n, 2 * n * B);
 		BLA_HIP(hipGetLastError());
 		return BLA_OK;
 	};
