@@ -351,11 +351,13 @@ def run_mnist(bla, dist, world, rank, stream, steps, warmup, barrier, per_gpu_ba
 def committed_traffic(target):
     """HBM-side traffic per iteration of a secondary / tertiary workload from the committed rocprofv3 --pmc summary of the same workload
     (profiles/r02/<target>.summary.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; it cannot be collected from inside this process)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02", target + ".summary.json")))
-        return int(d["iteration"]["traffic_bytes"]), f"profiles/r02/{target}.summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for rnd in ("r03", "r02"):          # the newest committed summary of this workload
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", rnd, target + ".summary.json")))
+            return int(d["iteration"]["traffic_bytes"]), f"profiles/{rnd}/{target}.summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def run_conv(bla, stream, barrier, steps=20, warmup=5):
@@ -625,13 +627,15 @@ def main():
     }
     # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (it cannot be collected from
     # inside this process); the committed summary applies when it was taken on this exact kernel and size
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm4096_traffic.json")))
-        if n == 4096 and tr["kernel"] == out["config"]["kernel"]:
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_gemm4096_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r03_gemm4096_traffic.json", "r01_gemm4096_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if n == 4096 and tr["kernel"] == out["config"]["kernel"]:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     # the GPU workloads are timed back to back; the CPU baselines (tens of seconds of host work) come after them
     sec, fault, ter, conv_arrays = None, None, None, None
     if args.mnist_steps > 0:

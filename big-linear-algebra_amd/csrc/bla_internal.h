@@ -79,6 +79,17 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
                                 int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend);
 
+// bla_unet.hip: the batched ResNet block with the time-embedding projection hoisted out (bla_unet_model.hip forms all blocks' projections / time gradients in
+// one launch each): RESNET_TDENSE_READY = ws->tdense is already filled; RESNET_DEFER_TIME_GRADS = only the per-image channel sums go to d_dtb
+enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
+bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
+                                 float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
+bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                  const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
+bla_status resnet_backward_batched(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                   const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h, int w,
+                                   int cin, int cout, int k, int tdim, int group_size, int flags);
+
 // "My gradients are ready", posted by the LAST gradient kernel of a data-parallel step instead of by the exchange launch behind it (every
 // step paid a launch boundary before any peer could start reading).  The block lives in device memory (built by bla_dp_connect); a launch that is
 // handed it counts its workgroups in, and the last one to finish stores epoch + 1 into every peer's flag word for this rank -- each workgroup after

@@ -344,6 +344,11 @@ bla_status bla_sum_f32(void* stream, float* d_out, const float* d_a, const float
  * the time-embedding dense layer is a 1 x T . T x Cout product with the bias in the epilogue. */
 bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
                                   const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size) {
+	return resnet_forward_single(stream, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, 0);
+}
+}  // extern "C"
+bla_status bla::resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                      const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags) {
 	BLA_ENTER();
 	BLA_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
 	BLA_REQUIRE(d_x && d_temb && p && d_drop && ws && d_result && p->conv1 && p->conv2 && p->time_w && p->time_b, BLA_ERR_INVALID, "null operand");
@@ -351,9 +356,11 @@ bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d
 	const int hw = h * w;
 	st = bla_group_norm_relu_f32(stream, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw); if (st) return st;         // :1046-1047
 	// the time-embedding projection first, so that its per-channel add (:1053) rides in the store of the first convolution (:1048)
-	bla_gemm_epilogue ep = {};
-	ep.alpha = 1.f; ep.bias_col = p->time_b;
-	st = bla_gemm_f32(stream, 0, 0, 1, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st; // :1051-1052
+	if (!(flags & RESNET_TDENSE_READY)) {
+		bla_gemm_epilogue ep = {};
+		ep.alpha = 1.f; ep.bias_col = p->time_b;
+		st = bla_gemm_f32(stream, 0, 0, 1, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st; // :1051-1052
+	}
 	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr); if (st) return st;   // :1048,1053
 	st = group_norm_relu_dropout(stream, ws->c1, ws->relu2, d_drop, ws->dp, ws->sd2, ws->mu2, cout, group_size, hw); if (st) return st;   // :1056-1058, one pass
 	const float* r = d_x;
@@ -364,6 +371,7 @@ bla_status bla_resnet_forward_f32(void* stream, const float* d_x, const float* d
 	// second convolution (:1059) with the residual sum (:1067-1071) in its store: c2 = conv, result = c2 + r
 	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result);
 }
+extern "C" {
 
 bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
                                    const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_del_x, int h, int w,
@@ -434,16 +442,32 @@ bla_status bla_group_norm_ddx_gated_batched_f32(void* stream, int batch, const f
 
 bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
                                           const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size) {
-	if (batch == 1) return bla_resnet_forward_f32(stream, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size);
+	return resnet_forward_batched(stream, batch, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, 0);
+}
+bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                           const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
+                                           int w, int cin, int cout, int k, int tdim, int group_size) {
+	return resnet_backward_batched(stream, batch, d_del_out, d_x, d_temb, p, ws, g, sc, d_dtb, d_del_x, h, w, cin, cout, k, tdim, group_size, 0);
+}
+
+}  // extern "C"
+
+// flags (bla_internal.h): RESNET_TDENSE_READY -- ws->tdense already holds temb . W_t + b_t (the U-Net forms all 18 blocks' projections in one launch before the
+// first block); RESNET_DEFER_TIME_GRADS -- d_dtb receives the per-image channel sums and the caller forms time_w / time_b gradients from them later
+bla_status bla::resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
+                                       const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags) {
+	if (batch == 1) return resnet_forward_single(stream, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, flags);
 	BLA_ENTER();
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
 	BLA_REQUIRE(d_x && d_temb && p && d_drop && ws && d_result && p->conv1 && p->conv2 && p->time_w && p->time_b, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && ws->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and workspace");
 	const int hw = h * w;
 	st = gn_relu_b(stream, batch, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw, nullptr, nullptr); if (st) return st;            // :1046-1047
-	bla_gemm_epilogue ep = {};
-	ep.alpha = 1.f; ep.bias_col = p->time_b;
-	st = bla_gemm_f32(stream, 0, 0, batch, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st;      // :1051-1052, one row per image
+	if (!(flags & RESNET_TDENSE_READY)) {
+		bla_gemm_epilogue ep = {};
+		ep.alpha = 1.f; ep.bias_col = p->time_b;
+		st = bla_gemm_f32(stream, 0, 0, batch, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st;      // :1051-1052, one row per image
+	}
 	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout); if (st) return st;   // :1048,1053
 	st = gn_relu_b(stream, batch, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw, d_drop, ws->dp); if (st) return st;          // :1056-1058
 	const float* r = d_x;
@@ -454,9 +478,9 @@ bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* 
 	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0);            // :1059,1067-1071
 }
 
-bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
-                                           const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
-                                           int w, int cin, int cout, int k, int tdim, int group_size) {
+bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
+                                        const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
+                                        int w, int cin, int cout, int k, int tdim, int group_size, int flags) {
 	if (batch == 1 && d_del_x) return bla_resnet_backward_f32(stream, d_del_out, d_x, d_temb, p, ws, g, sc, d_del_x, h, w, cin, cout, k, tdim, group_size);
 	BLA_ENTER();
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
@@ -468,8 +492,10 @@ bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float*
 	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
 	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
 	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
-	st = batch_sum(stream, d_dtb, g->time_b, batch, (size_t)cout); if (st) return st;
-	st = bla_gemm_f32(stream, 1, 0, tdim, cout, batch, d_temb, tdim, d_dtb, cout, g->time_w, cout, nullptr); if (st) return st;
+	if (!(flags & RESNET_DEFER_TIME_GRADS)) {
+		st = batch_sum(stream, d_dtb, g->time_b, batch, (size_t)cout); if (st) return st;
+		st = bla_gemm_f32(stream, 1, 0, tdim, cout, batch, d_temb, tdim, d_dtb, cout, g->time_w, cout, nullptr); if (st) return st;
+	}
 	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
 	// gradients and the last norm gradient are not formed, the weight gradients are
 	st = bla_conv2d_backward_batched_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1);   // :1202-1205
@@ -481,5 +507,3 @@ bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float*
 	}
 	return BLA_OK;
 }
-
-}  // extern "C"

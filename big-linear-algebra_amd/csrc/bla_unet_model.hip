@@ -33,8 +33,11 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
+	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
+// one ResNet block's time-embedding projection (model/cifar_unet.c:1051-1052) and its gradients (:1191-1199); all 18 run as one launch each way
+struct TimeJob { const float* w; const float* bias; float* tdense; const float* dtb; float* g_tw; float* g_tb; int cout; };
 struct Att {
 	int c, h, w;
 	size_t wq, wk, wv, wo, bias;
@@ -66,6 +69,7 @@ struct bla_unet {
 	unsigned char* zero_drop = nullptr;
 	// backward
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
+	TimeJob* time_jobs = nullptr;                // device, one per ResNet block (batch > 1)
 	float *dtb = nullptr, *partials = nullptr;   // batched blocks: per-image time-bias sums [B][Cout], per-image attention weight gradients [B][C*d]
 	bla_resnet_scratch sc = {};
 	bla_attention_ws agrad = {};
@@ -120,8 +124,8 @@ bla_status alloc_res(bla_unet* m, Res& r) {
 	    (st = dalloc(m, &r.ws.dp, r.cout * hw)) || (st = dalloc(m, &r.ws.c2, r.cout * hw)) || (st = dalloc(m, &r.result, r.cout * hw)))
 		return st;
 	r.ws.res = nullptr;
-	if (r.cin != r.cout) st = dalloc(m, &r.ws.res, r.cout * hw);
-	return st;
+	if (r.cin != r.cout && (st = dalloc(m, &r.ws.res, r.cout * hw))) return st;
+	return m->batch > 1 ? dalloc(m, &r.dtb, (size_t)r.cout * m->batch) : BLA_OK;
 }
 bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s1, size_t d) {
 	bla_status st;
@@ -133,6 +137,40 @@ bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s1, size_t d) 
 	return BLA_OK;
 }
 
+// tdense[b][c] = sum_t temb[b][t] W[t][c] + bias[c] for every block at once: grid (block, 8 images), thread = output channel; the eight embedding rows in LDS
+__global__ void __launch_bounds__(256) time_dense_all_kernel(const TimeJob* __restrict__ jobs, const float* __restrict__ temb, int batch, int tdim) {
+	extern __shared__ float te[];             // [8][tdim]
+	const TimeJob j = jobs[blockIdx.x];
+	const int b0 = blockIdx.y * 8, nb = min(8, batch - b0);
+	for (int e = threadIdx.x; e < 8 * tdim; e += 256) te[e] = e < nb * tdim ? temb[(size_t)b0 * tdim + e] : 0.f;
+	__syncthreads();
+	for (int c = threadIdx.x; c < j.cout; c += 256) {
+		float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+		for (int t = 0; t < tdim; t++) {
+			const float wv = j.w[(size_t)t * j.cout + c];
+#pragma unroll
+			for (int i = 0; i < 8; i++) acc[i] = fmaf(te[i * tdim + t], wv, acc[i]);
+		}
+		const float bv = j.bias[c];
+		for (int i = 0; i < nb; i++) j.tdense[(size_t)(b0 + i) * j.cout + c] = acc[i] + bv;
+	}
+}
+// g_tw[t][c] = sum_b temb[b][t] dtb[b][c], g_tb[c] = sum_b dtb[b][c] (images in order): grid (block, tdim / 8), thread = channel
+__global__ void __launch_bounds__(256) time_grads_all_kernel(const TimeJob* __restrict__ jobs, const float* __restrict__ temb, int batch, int tdim) {
+	const TimeJob j = jobs[blockIdx.x];
+	const int t0 = blockIdx.y * 8, nt = min(8, tdim - t0);
+	for (int c = threadIdx.x; c < j.cout; c += 256) {
+		float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+		for (int b = 0; b < batch; b++) {
+			const float d = j.dtb[(size_t)b * j.cout + c];
+			sb += d;
+#pragma unroll
+			for (int i = 0; i < 8; i++) acc[i] = fmaf(i < nt ? temb[(size_t)b * tdim + t0 + i] : 0.f, d, acc[i]);
+		}
+		for (int i = 0; i < nt; i++) j.g_tw[(size_t)(t0 + i) * j.cout + c] = acc[i];
+		if (blockIdx.y == 0) j.g_tb[c] = sb;
+	}
+}
 // del_Y = 2 (prediction - noise), model/cifar_unet.c:1353-1364
 __global__ void __launch_bounds__(256) unet_loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ noise, float* __restrict__ g, int n) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] = 2.f * (out[i] - noise[i]);
@@ -273,6 +311,18 @@ bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, i
 	m->owned.push_back(z);
 	m->zero_drop = (unsigned char*)z;
 	BLA_HIP(hipMemsetAsync(z, 0, zero_bytes, ctx().stream));
+	{   // the 18 time-embedding projections (and, for a batch, their gradients) as one launch each way: the jobs' addresses are fixed from here on
+		TimeJob jobs[18];
+		for (int i = 0; i < 18; i++) {
+			const Res& r = m->res[i];
+			jobs[i] = TimeJob{m->params + r.tw, m->params + r.tb, r.ws.tdense, r.dtb, m->grads + r.tw, m->grads + r.tb, r.cout};
+		}
+		void* tj = nullptr;
+		BLA_HIP(hipMalloc(&tj, sizeof jobs));
+		m->owned.push_back(tj);
+		m->time_jobs = (TimeJob*)tj;
+		BLA_HIP(hipMemcpy(tj, jobs, sizeof jobs, hipMemcpyHostToDevice));
+	}
 	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	*out = m;
 	return BLA_OK;
@@ -318,9 +368,14 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 		Res& r = m->res[i];
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		// the dropout decisions: block by block in forward order, inside a block image by image
-		return bla_resnet_forward_batched_f32(stream, B, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off * B, &r.ws, r.result, r.h, r.w, r.cin,
-		                                      r.cout, c.kernel, c.time_dim, c.group_size);
+		return resnet_forward_batched(stream, B, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off * B, &r.ws, r.result, r.h, r.w, r.cin,
+		                              r.cout, c.kernel, c.time_dim, c.group_size, m->time_jobs ? RESNET_TDENSE_READY : 0);
 	};
+	if (m->time_jobs) {   // every block's time-embedding projection depends on the embedding alone: one launch for the 18 of them
+		hipLaunchKernelGGL(time_dense_all_kernel, dim3(18, (unsigned)((B + 7) / 8)), dim3(256), (size_t)8 * c.time_dim * sizeof(float), s, m->time_jobs, d_time_embedding, B,
+		                   c.time_dim);
+		BLA_HIP(hipGetLastError());
+	}
 	auto att = [&](int i, const float* in) -> bla_status {
 		Att& a = m->att[i];
 		return bla_attention_forward_batched_f32(stream, B, in, P + a.wq, P + a.wk, P + a.wv, P + a.wo, P + a.bias, &a.fwd, a.out, a.c, a.h * a.w, c.key_dim);
@@ -390,7 +445,8 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		Res& r = m->res[i];
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
-		return bla_resnet_backward_batched_f32(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim, c.group_size);
+		return resnet_backward_batched(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, B > 1 ? r.dtb : m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim,
+		                               c.group_size, B > 1 ? RESNET_DEFER_TIME_GRADS : 0);
 	};
 	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Att& a = m->att[i];
@@ -460,6 +516,10 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 	TRY(bla_add_f32(stream, a, m->gskip[3], n0 * B));
 	TRY(res(1, a, m->res[0].result, b));
 	TRY(res(0, b, m->last_x, nullptr));   // nothing consumes the gradient of the image: the first block forms its weight gradients only
+	if (B > 1) {   // the 18 blocks' time-weight / time-bias gradients from the channel sums each block left behind (:1191-1199)
+		hipLaunchKernelGGL(time_grads_all_kernel, dim3(18, (unsigned)((c.time_dim + 7) / 8)), dim3(256), 0, s, m->time_jobs, temb, B, c.time_dim);
+		BLA_HIP(hipGetLastError());
+	}
 	return BLA_OK;
 }
 #undef TRY
