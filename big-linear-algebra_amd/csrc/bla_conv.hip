@@ -249,13 +249,21 @@ constexpr int kGnSlice = 2048, kGnSliceThreads = 256;
 // forward pass of a large group, same slicing: partial sum x and sum x^2 in fp64 (x^2 is exact in fp64), then every slice forms
 //   mean = (float)(sum x / n)   and   variance about that float mean = (sum x^2 - 2 mean sum x + n mean^2) / n
 // -- the two passes of lib/norm.c:26-37 from one pass over memory -- and normalises its part.
+template <bool VEC>   // VEC: 16-byte loads / stores (hw a multiple of 4, 16-byte aligned tensors) -- the scalar form moved 3.3 TB/s
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_stats_kernel(const float* __restrict__ in, int channels, int group_size, int hw, double2* partials) {
 	const int g = blockIdx.y, slice = blockIdx.x;
 	const int nch = min(group_size, channels - g * group_size);
 	const size_t off = (size_t)g * group_size * hw;
 	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
 	double a = 0, b = 0;
-	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) { double x = in[off + i]; a += x; b += x * x; }
+	if (VEC) {
+		for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * kGnSliceThreads) {
+			const float4 v = *reinterpret_cast<const float4*>(in + off + i);
+			const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+			a += x0; b += x0 * x0; a += x1; b += x1 * x1; a += x2; b += x2 * x2; a += x3; b += x3 * x3;
+		}
+	} else
+		for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) { double x = in[off + i]; a += x; b += x * x; }
 	__shared__ double sh[2][kGnSliceThreads / 64];
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_stats_kernel(const
 	}
 }
 
-template <bool RELU>
+template <bool RELU, bool VEC>
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
                                                                             float* __restrict__ means, int channels, int group_size, int hw,
                                                                             const unsigned char* __restrict__ drop, float* __restrict__ dropped,
@@ -283,6 +291,20 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const
 	const double m = (double)mean;
 	const float var = (float)((b - 2.0 * m * a + (double)n * m * m) / (double)n);
 	if (slice == 0 && threadIdx.x == 0) { means[g] = mean; stdevs[g] = var; }
+	if (VEC) {
+		for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * kGnSliceThreads) {
+			const float4 v = *reinterpret_cast<const float4*>(in + off + i);
+			float y[4] = {(v.x - mean) / var, (v.y - mean) / var, (v.z - mean) / var, (v.w - mean) / var};
+#pragma unroll
+			for (int e = 0; e < 4; e++) y[e] = RELU && y[e] < 0.f ? 0.f : y[e];
+			*reinterpret_cast<float4*>(out + off + i) = make_float4(y[0], y[1], y[2], y[3]);
+			if (dropped) {
+				const uchar4 d = *reinterpret_cast<const uchar4*>(drop + off + i);
+				*reinterpret_cast<float4*>(dropped + off + i) = make_float4(d.x ? 0.f : y[0], d.y ? 0.f : y[1], d.z ? 0.f : y[2], d.w ? 0.f : y[3]);
+			}
+		}
+		return;
+	}
 	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
 		float y = (in[off + i] - mean) / var;
 		y = RELU && y < 0.f ? 0.f : y;
@@ -291,6 +313,7 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const
 	}
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_stats_kernel(const float* __restrict__ source, const float* __restrict__ data,
                                                                                 const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
                                                                                 int group_size, int hw, const float* __restrict__ relu_gate, double2* partials) {
@@ -300,6 +323,21 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_stats_kernel(c
 	const int n = nch * hw, lo = slice * kGnSlice, hi = min(n, lo + kGnSlice);
 	const float mean = means[g], sd = stdevs[g];
 	double gs = 0, gws = 0;
+	if (VEC) {
+		for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * kGnSliceThreads) {
+			const float4 dv = *reinterpret_cast<const float4*>(data + off + i), sv4 = *reinterpret_cast<const float4*>(source + off + i);
+			float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
+			if (relu_gate) gt = *reinterpret_cast<const float4*>(relu_gate + off + i);
+			const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, ss[4] = {sv4.x, sv4.y, sv4.z, sv4.w}, gg[4] = {gt.x, gt.y, gt.z, gt.w};
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const float wgt = (dd[e] - mean) / sd;
+				const float sv = relu_gate && gg[e] <= 0.f ? 0.f : ss[e];
+				gs += sv;
+				gws += (double)wgt * sv;
+			}
+		}
+	} else
 	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
 		float wgt = (data[off + i] - mean) / sd;
 		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
@@ -318,6 +356,7 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_stats_kernel(c
 	}
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_apply_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
                                                                                 const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
                                                                                 int group_size, int hw, const float* __restrict__ relu_gate,
@@ -330,6 +369,25 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_apply_kernel(c
 	double a = 0, b = 0;
 	for (unsigned i = 0; i < gridDim.x; i++) { double2 q = partials[(size_t)g * gridDim.x + i]; a += q.x; b += q.y; }   // slice order: same totals in every workgroup
 	const float fgs = (float)(a / (double)n), fgws = (float)(b / (double)n);
+	if (VEC) {
+		for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * kGnSliceThreads) {
+			const float4 dv = *reinterpret_cast<const float4*>(data + off + i), sv4 = *reinterpret_cast<const float4*>(source + off + i);
+			float4 gt = make_float4(1.f, 1.f, 1.f, 1.f), ad = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (relu_gate) gt = *reinterpret_cast<const float4*>(relu_gate + off + i);
+			if (addend) ad = *reinterpret_cast<const float4*>(addend + off + i);
+			const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, ss[4] = {sv4.x, sv4.y, sv4.z, sv4.w}, gg[4] = {gt.x, gt.y, gt.z, gt.w}, aa[4] = {ad.x, ad.y, ad.z, ad.w};
+			float r[4];
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const float nv = (dd[e] - mean) / sd;
+				const float sv = relu_gate && gg[e] <= 0.f ? 0.f : ss[e];
+				const float d = (sv - fgs - nv * fgws) / sd;
+				r[e] = addend ? d + aa[e] : d;
+			}
+			*reinterpret_cast<float4*>(dest + off + i) = make_float4(r[0], r[1], r[2], r[3]);
+		}
+		return;
+	}
 	for (int i = lo + (int)threadIdx.x; i < hi; i += kGnSliceThreads) {
 		float nv = (data[off + i] - mean) / sd;
 		float sv = relu_gate && relu_gate[off + i] <= 0.f ? 0.f : source[off + i];
@@ -903,9 +961,16 @@ static bla_status launch_group_norm(hipStream_t s, const float* in, float* out, 
 		void* ws;
 		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
 		if (st) return st;
-		hipLaunchKernelGGL(group_norm_stats_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
-		hipLaunchKernelGGL(group_norm_apply_kernel<RELU>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
-		                   dropped, (const double2*)ws);
+		const bool vec = hw % 4 == 0 && ((uintptr_t)in | (uintptr_t)out | (uintptr_t)dropped) % 16 == 0 && (uintptr_t)drop % 4 == 0;
+		if (vec) {
+			hipLaunchKernelGGL(group_norm_stats_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
+			hipLaunchKernelGGL((group_norm_apply_kernel<RELU, true>), dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
+			                   dropped, (const double2*)ws);
+		} else {
+			hipLaunchKernelGGL(group_norm_stats_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
+			hipLaunchKernelGGL((group_norm_apply_kernel<RELU, false>), dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
+			                   dropped, (const double2*)ws);
+		}
 	}
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;
@@ -923,10 +988,18 @@ static bla_status launch_group_norm_ddx(hipStream_t s, const float* source, floa
 		void* ws;
 		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
 		if (st) return st;
-		hipLaunchKernelGGL(group_norm_ddx_stats_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
-		                   relu_gate, (double2*)ws);
-		hipLaunchKernelGGL(group_norm_ddx_apply_kernel, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
-		                   relu_gate, addend, (const double2*)ws);
+		const bool vec = hw % 4 == 0 && ((uintptr_t)source | (uintptr_t)dest | (uintptr_t)data | (uintptr_t)relu_gate | (uintptr_t)addend) % 16 == 0;
+		if (vec) {
+			hipLaunchKernelGGL(group_norm_ddx_stats_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
+			                   relu_gate, (double2*)ws);
+			hipLaunchKernelGGL(group_norm_ddx_apply_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
+			                   relu_gate, addend, (const double2*)ws);
+		} else {
+			hipLaunchKernelGGL(group_norm_ddx_stats_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
+			                   relu_gate, (double2*)ws);
+			hipLaunchKernelGGL(group_norm_ddx_apply_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
+			                   relu_gate, addend, (const double2*)ws);
+		}
 	}
 	BLA_HIP(hipGetLastError());
 	return BLA_OK;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement pass on one MI355X (run through gpurun from the repo root, one PART per call -- a call is limited to 20 minutes):
-#   a: bench line, rehearsals of the N > 1 bench path on the shared GPU (2 and 6 ranks, gloo on the host side, the peer-read exchange between the processes,
+#   a: bench line, rehearsals of the N > 1 bench path on the shared GPU (2 and 4 ranks, gloo on the host side, the peer-read exchange between the processes,
 #      BLA_BENCH_STRICT=1), data-parallel step floor, convolution shapes, batched U-Net (+ its rocprofv3 kernel statistics)
 #   b: GEMM sweep, elementwise bandwidth, the bench under rocprofv3 and the headline kernel's three counter passes (FETCH_SIZE / WRITE_SIZE / MFMA busy;
 #      the program itself after `--`)
@@ -10,7 +10,7 @@ out=${1:-gpurun_out/r03m}; part=${2:-a}; mkdir -p $out
 export TMPDIR=/tmp
 if [ $part = a ]; then
   python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-  for n in 2 6; do      # (the one-GPU box lets at most 6 processes use the card: the 8-rank form of the same command cannot be rehearsed there)
+  for n in 2 4; do      # (the one-GPU box lets at most 6 processes use the card, the launcher counts as one or two: 8 ranks of the same command cannot be rehearsed there)
     BLA_BENCH_SHARE_GPU=1 BLA_BENCH_BACKEND=gloo BLA_BENCH_EXCHANGE=direct BLA_BENCH_STRICT=1 BLA_DP_MAX_BLOCKS=48 GPU_MAX_HW_QUEUES=16 HSA_ENABLE_IPC_MODE_LEGACY=0 \
       timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29517 + n)) \
       bench.py --gpus $n --steps 10 --warmup 5 --mnist-steps 100 > $out/bench_share$n.json 2> $out/bench_share$n.err; echo "bench share$n rc=$?"
