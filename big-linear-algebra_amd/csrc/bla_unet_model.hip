@@ -137,22 +137,33 @@ bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s1, size_t d) 
 	return BLA_OK;
 }
 
-// tdense[b][c] = sum_t temb[b][t] W[t][c] + bias[c] for every block at once: grid (block, 8 images), thread = output channel; the eight embedding rows in LDS
+// tdense[b][c] = sum_t temb[b][t] W[t][c] + bias[c] for every block at once: grid (block, 8 images, 64 channels); a workgroup = 64 channels x 4 quarters of
+// the t range, the eight embedding rows in LDS, the quarters folded through LDS in quarter order (t ascending inside a quarter)
 __global__ void __launch_bounds__(256) time_dense_all_kernel(const TimeJob* __restrict__ jobs, const float* __restrict__ temb, int batch, int tdim) {
-	extern __shared__ float te[];             // [8][tdim]
+	extern __shared__ float te[];             // [8][tdim], then [4][8][64] partial sums
+	float* part = te + 8 * tdim;
 	const TimeJob j = jobs[blockIdx.x];
+	const int c0 = blockIdx.z * 64;
+	if (c0 >= j.cout) return;                 // (whole workgroups: before any barrier)
 	const int b0 = blockIdx.y * 8, nb = min(8, batch - b0);
 	for (int e = threadIdx.x; e < 8 * tdim; e += 256) te[e] = e < nb * tdim ? temb[(size_t)b0 * tdim + e] : 0.f;
 	__syncthreads();
-	for (int c = threadIdx.x; c < j.cout; c += 256) {
-		float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-		for (int t = 0; t < tdim; t++) {
+	const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6, c = c0 + lane;
+	const int per = (tdim + 3) / 4, t0 = quarter * per, t1 = min(tdim, t0 + per);
+	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	if (c < j.cout)
+		for (int t = t0; t < t1; t++) {
 			const float wv = j.w[(size_t)t * j.cout + c];
 #pragma unroll
 			for (int i = 0; i < 8; i++) acc[i] = fmaf(te[i * tdim + t], wv, acc[i]);
 		}
-		const float bv = j.bias[c];
-		for (int i = 0; i < nb; i++) j.tdense[(size_t)(b0 + i) * j.cout + c] = acc[i] + bv;
+#pragma unroll
+	for (int i = 0; i < 8; i++) part[(quarter * 8 + i) * 64 + lane] = acc[i];
+	__syncthreads();
+	for (int e = threadIdx.x; e < 8 * 64; e += 256) {
+		const int i = e >> 6, l = e & 63;
+		if (i < nb && c0 + l < j.cout)
+			j.tdense[(size_t)(b0 + i) * j.cout + c0 + l] = ((part[(0 * 8 + i) * 64 + l] + part[(1 * 8 + i) * 64 + l]) + (part[(2 * 8 + i) * 64 + l] + part[(3 * 8 + i) * 64 + l])) + j.bias[c0 + l];
 	}
 }
 // g_tw[t][c] = sum_b temb[b][t] dtb[b][c], g_tb[c] = sum_b dtb[b][c] (images in order): grid (block, tdim / 8), thread = channel
@@ -372,8 +383,10 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 		                              r.cout, c.kernel, c.time_dim, c.group_size, m->time_jobs ? RESNET_TDENSE_READY : 0);
 	};
 	if (m->time_jobs) {   // every block's time-embedding projection depends on the embedding alone: one launch for the 18 of them
-		hipLaunchKernelGGL(time_dense_all_kernel, dim3(18, (unsigned)((B + 7) / 8)), dim3(256), (size_t)8 * c.time_dim * sizeof(float), s, m->time_jobs, d_time_embedding, B,
-		                   c.time_dim);
+		int max_cout = 0;
+		for (int i = 0; i < 18; i++) max_cout = std::max(max_cout, m->res[i].cout);
+		hipLaunchKernelGGL(time_dense_all_kernel, dim3(18, (unsigned)((B + 7) / 8), (unsigned)((max_cout + 63) / 64)), dim3(256),
+		                   ((size_t)8 * c.time_dim + 4 * 8 * 64) * sizeof(float), s, m->time_jobs, d_time_embedding, B, c.time_dim);
 		BLA_HIP(hipGetLastError());
 	}
 	auto att = [&](int i, const float* in) -> bla_status {

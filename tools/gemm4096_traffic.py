@@ -30,8 +30,11 @@ if fetch is not None and write is not None:
     out.update(fetch_bytes_raw=fetch * 1024, fetch_bytes_corrected=2 * fetch * 1024, write_bytes=write * 1024, hbm_bytes_per_launch=2 * fetch * 1024 + write * 1024,
                algorithmic_bytes_per_launch=3 * 4096 * 4096 * 4)
 if busy is not None and active:
-    # SQ_VALU_MFMA_BUSY_CYCLES sums over the SIMDs it samples; the ratio to GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs is the busy fraction the guide describes
-    out.update(SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=active, mfma_busy_over_active=busy / active)
+    # busy = SQ_VALU_MFMA_BUSY_CYCLES (summed over 1,024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1,024) -- tools/mfma_busy_summary.py.  The profiler's per-dispatch
+    # value saturates at 2^31, which this launch reaches (2.2 M cycles x 1,024 SIMDs x 0.94): then the figure is a LOWER bound and the unsaturated one comes from
+    # the same kernel at a shorter contraction (profiles/r03_mfma_busy_gemm_conv.txt: 4096 x 4096 x 1536)
+    cyc = active / 8
+    out.update(SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=active, mfma_pipe_busy=busy / (cyc * 1024), mfma_counter_saturated=bool(busy >= 2 ** 31 - 1))
 out["note"] = ("separate --pmc passes on the final round-3 tree (tools/measure_r03.sh): `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace "
                "-- python3 bench.py --no-cpu-baseline --mnist-steps 0 --conv-steps 0 --steps 10 --warmup 5`; Infinity-Cache hits are counted in FETCH_SIZE, so this is "
                "L2-fill traffic (DESIGN.md 3.1: 256 tiles of 256x256, one per CU, (8 + 4) panels x 4 MiB x 8 XCDs = 403 MB; both operands fit the 256 MiB Infinity Cache)")

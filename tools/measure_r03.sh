@@ -31,6 +31,12 @@ elif [ $part = b ]; then
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/gemm4096_mfma -- python3 bench.py --no-cpu-baseline --mnist-steps 0 --conv-steps 0 --steps 10 --warmup 5 > $out/gemm4096_mfma.json 2> $out/gemm4096_mfma.err; echo "pmc mfma rc=$?"
   python3 tools/gemm4096_traffic.py $out > $out/r03_gemm4096_traffic.json
 else
+  for shape in "4096 4096 1536" "4096 4096 4096"; do      # the headline kernel's matrix-pipe counter below its 2^31 saturation, and at the headline size
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/busy_${shape// /x} -- python3 tools/gemm_rect.py $shape 10 > $out/busy_${shape// /x}.txt 2>&1
+    python3 tools/mfma_busy_summary.py $out/busy_${shape// /x} 100 >> $out/mfma_busy.txt 2>&1
+  done
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/busy_conv128 -- python3 tools/profile_targets.py conv128 5 > $out/busy_conv128.txt 2>&1
+  python3 tools/mfma_busy_summary.py $out/busy_conv128 >> $out/mfma_busy.txt 2>&1; echo "busy rc=$?"
   bash tools/profile_r02.sh $out/prof conv128 conv256 conv8 convs2 mnist mnist_dp softmax_cols add > $out/prof.log 2>&1; echo "profiles rc=$?"
   rm -f $out/prof/*/*/*/*_kernel_trace.csv
 fi
