@@ -6,7 +6,7 @@ Prints a JSON line with the algorithmic bytes and FLOPs of ONE iteration, which 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/profile_targets.py conv128 5
 
 targets: conv128 / conv256 (batch of 64, forward + backward), conv8 (256->256 @8x8 x64), convs2 (128->256 @32x32 stride 2 x64),
-mnist (fused-update step), mnist_dp (world-1 data-parallel step), softmax_cols, transpose, add, colsum, rowsum (8192 x 8192)"""
+mnist (fused-update step), mnist_dp (world-1 data-parallel step), softmax_cols, transpose, add, colsum, rowsum (8192 x 8192; softmax_cols4096 etc.: 4096 x 4096)"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +47,8 @@ elif target in ("mnist", "mnist_dp"):
         ex = mn.Exchange(0, 1, nn.count)
         run = lambda: nn.dp_step(ex, graph=False)
 else:
-    R = 8192; n = R * R
+    R = 4096 if target.endswith("4096") else 8192; n = R * R
+    target = target.replace("4096", "")
     a = bla.to_device(uniform(1, (R, R), -1, 1, np.float32)); o = bla.empty((R, R)); small = bla.empty((R,))
     if target == "softmax_cols":
         info.update(bytes=8.0 * n); run = lambda: chk(L.bla_softmax_cols_f32(st, a.ptr, R, R))
