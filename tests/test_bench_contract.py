@@ -1,5 +1,5 @@
 """bench.py's one-line JSON contract: the keys the driver reads, BASELINE.json's metric, the `roofline` and `cpu_baseline` objects.
-CPU: the committed line of the last measurement pass (profiles/r02_bench_default_output.json).  GPU: a short live run."""
+CPU: the committed line of the last measurement pass (profiles/r03_bench_default_output.json).  GPU: a short live run."""
 import json
 import os
 import subprocess
@@ -35,11 +35,29 @@ def check_line(d, with_cpu_baseline):
         for obj in (d, sec, ter, un):
             for k in CPU:
                 assert k in obj["cpu_baseline"], k
-        assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 1
+        # the three timed CPU baselines are the reference itself (oracle/_ref), one core each; the U-Net's cites the reference program's own run
+        for obj in (d, sec, ter):
+            assert obj["cpu_baseline"]["kind"] == "reference" and obj["cpu_baseline"]["cores"] == 1, obj["cpu_baseline"]
+        assert un["cpu_baseline"]["kind"] == "reference"
+        # the pass the U-Net figure comes from is checked against the committed fp64 prediction of image 0 (tests/golden/unet_refconst.npz)
+        assert 0 < un["prediction_rel_err_vs_oracle_image0"] <= 2 * un["reference_fp32_distance"]
+        assert d["roofline"]["traffic"] and "r03_gemm4096_traffic.json" in d["roofline"]["traffic_source"]
+        assert ter["roofline"]["traffic"] and "profiles/r03/conv128.summary.json" in ter["roofline"]["traffic_source"]
 
 
 def test_committed_bench_line_keeps_the_contract():
-    check_line(json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default_output.json"))), True)
+    check_line(json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default_output.json"))), True)
+
+
+def test_committed_rehearsals_of_the_multi_rank_path():
+    """bench.py --gpus N under torch.distributed.run with the ranks sharing the one GPU (tools/measure_r03.sh part a, BLA_BENCH_STRICT=1): the line of rank 0 keeps
+    the contract's shape, whole-job value = N replicas, no fault or fallback key set."""
+    for name, n in (("r03_bench_two_ranks_shared_gpu_rehearsal.json", 2), ("r03_bench_four_ranks_shared_gpu_rehearsal.json", 4)):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["n_gpus"] == n and d["scaling"] == "weak" and d["config"]["parallelism"] == f"replicas x{n}"
+        assert abs(d["value"] - n * 2 * 4096 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) <= 2e-3 * d["value"]
+        sec = d["secondary"]
+        assert sec["value"] > 0 and not sec.get("exchange_fallback") and sec.get("exchange_fault") is None and sec.get("rccl_fault") is None and "direct" in sec["legs"]
 
 
 @pytest.mark.gpu
