@@ -191,10 +191,19 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_kernel(const float* __r
 // The register path of the kernel above at 16 bytes per thread: groups of up to 16,384 elements (a multiple of 4, 16-byte aligned), four float4 per
 // thread.  The U-Net's 16x16 / 8x8 / 4x4 maps at batch 64 are all of this kind (512 groups of 8,192 elements moved 3.7 TB/s in the scalar form).
 constexpr int kGnVec = 4;
+// a norm kernel's by-product: the four values it just stored, again at their place inside the zero-padded copy the convolution behind it gathers from
+// (PadOut, bla_internal.h; e = flat element index, a multiple of 4; rows are multiples of four pixels, so the four stay in one row)
+struct PadArgs { float* dst; int hw, w, wh, plane, ptl; };
+__device__ __forceinline__ void pad_store4(const PadArgs& pa, size_t e, float a, float b, float c, float d) {
+	const size_t pl = e / (unsigned)pa.hw;
+	const int pix = (int)(e - pl * (unsigned)pa.hw), y = pix / pa.w, x = pix - y * pa.w;
+	float* q = pa.dst + pl * (size_t)pa.plane + (size_t)y * pa.wh + x + pa.ptl;
+	q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+}
 template <bool RELU>
 __global__ void __launch_bounds__(kGnThreads) group_norm_vec_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
                                                                      float* __restrict__ means, int channels, int group_size, int hw,
-                                                                     const unsigned char* __restrict__ drop, float* __restrict__ dropped) {
+                                                                     const unsigned char* __restrict__ drop, float* __restrict__ dropped, PadArgs pa) {
 	const int g = blockIdx.x, t = threadIdx.x;
 	const int nch = min(group_size, channels - g * group_size);
 	const size_t off = (size_t)g * group_size * hw;
@@ -228,8 +237,13 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_vec_kernel(const float*
 		reinterpret_cast<float4*>(out + off)[j] = make_float4(y[0], y[1], y[2], y[3]);
 		if (dropped) {
 			const uchar4 d = reinterpret_cast<const uchar4*>(drop + off)[j];
-			reinterpret_cast<float4*>(dropped + off)[j] = make_float4(d.x ? 0.f : y[0], d.y ? 0.f : y[1], d.z ? 0.f : y[2], d.w ? 0.f : y[3]);
+			if (d.x) y[0] = 0.f;
+			if (d.y) y[1] = 0.f;
+			if (d.z) y[2] = 0.f;
+			if (d.w) y[3] = 0.f;
+			reinterpret_cast<float4*>(dropped + off)[j] = make_float4(y[0], y[1], y[2], y[3]);
 		}
+		if (pa.dst) pad_store4(pa, off + 4 * (size_t)j, y[0], y[1], y[2], y[3]);
 	}
 }
 __global__ void __launch_bounds__(kGnThreads) group_norm_ddx_vec_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
@@ -363,7 +377,7 @@ template <bool RELU, bool VEC>
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
                                                                             float* __restrict__ means, int channels, int group_size, int hw,
                                                                             const unsigned char* __restrict__ drop, float* __restrict__ dropped,
-                                                                            const double2* __restrict__ partials) {
+                                                                            const double2* __restrict__ partials, PadArgs pa) {
 	const int g = blockIdx.y, slice = blockIdx.x;
 	const int nch = min(group_size, channels - g * group_size);
 	const size_t off = (size_t)g * group_size * hw;
@@ -383,8 +397,13 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const
 			*reinterpret_cast<float4*>(out + off + i) = make_float4(y[0], y[1], y[2], y[3]);
 			if (dropped) {
 				const uchar4 d = *reinterpret_cast<const uchar4*>(drop + off + i);
-				*reinterpret_cast<float4*>(dropped + off + i) = make_float4(d.x ? 0.f : y[0], d.y ? 0.f : y[1], d.z ? 0.f : y[2], d.w ? 0.f : y[3]);
+				if (d.x) y[0] = 0.f;
+				if (d.y) y[1] = 0.f;
+				if (d.z) y[2] = 0.f;
+				if (d.w) y[3] = 0.f;
+				*reinterpret_cast<float4*>(dropped + off + i) = make_float4(y[0], y[1], y[2], y[3]);
 			}
+			if (pa.dst) pad_store4(pa, off + (size_t)i, y[0], y[1], y[2], y[3]);
 		}
 		return;
 	}
@@ -522,6 +541,9 @@ struct ConvArgs {
 	// data gradient on the window kernel: A is still to be made -- the forward kernels [F][C][3][3] (F = this product's K / 9, C = its M), flipped and
 	// re-ordered in one pass (window_order_flipped_kernel) instead of flip_kernels_kernel + window_order_kernels_kernel
 	const float* flip_src = nullptr;
+	// the caller already holds the zero-padded copy of `img` in this geometry's layout (conv_padded_layout: the norm kernel in front wrote it as a by-product):
+	// the padded-copy forward and the weight gradient read it instead of making their own
+	const float* padded_src = nullptr;
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -945,14 +967,18 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 			const int splits3 = gather3_splits(a.M, a.N * batch, a.K);
 			const size_t slab_bytes = splits3 > 1 ? ((size_t)splits3 * a.M * a.N * batch * sizeof(float) + 255) / 256 * 256 : 0;
 			void* ws;
-			st = ensure_workspace(slab_bytes + copy_floats * sizeof(float) + 64, &ws);   // [slabs][padded copy]
+			st = ensure_workspace(slab_bytes + (a.padded_src ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;
-			float* padded = (float*)((char*)ws + slab_bytes);
+			const float* padded = a.padded_src;
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
-			launch_pad_split(s, a.img, padded, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl, a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
-			BLA_HIP(hipGetLastError());
+			if (!padded) {
+				float* mine = (float*)((char*)ws + slab_bytes);
+				launch_pad_split(s, a.img, mine, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl, a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
+				BLA_HIP(hipGetLastError());
+				padded = mine;
+			}
 			const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
 			return gather_gemm(s, 3, batch, a.M, a.N * batch, a.K, a.A, a.lda, a.out, a.ldo, padded, taps, pix, pg.hh, pg.wh, a.N, (int)(a.g.c * pg.plane_floats),
 			                   a.ep_fused_tiled ? &gep : nullptr);
@@ -963,14 +989,18 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 			// transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const size_t slab_bytes = ((size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float) + 255) / 256 * 256;
 			void* ws;
-			st = ensure_workspace(slab_bytes + copy_floats * sizeof(float) + 64, &ws);   // [slabs][padded copy]
+			st = ensure_workspace(slab_bytes + (a.padded_src ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;
-			float* padded = (float*)((char*)ws + slab_bytes);
+			const float* padded = a.padded_src;
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
-			launch_pad_split(s, a.img, padded, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl, a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
-			BLA_HIP(hipGetLastError());
+			if (!padded) {
+				float* mine = (float*)((char*)ws + slab_bytes);
+				launch_pad_split(s, a.img, mine, (unsigned)(batch * a.g.c), a.g.h, a.g.w, a.g.pt, a.g.pl, a.g.s, (unsigned)pg.hh, (unsigned)pg.wh);
+				BLA_HIP(hipGetLastError());
+				padded = mine;
+			}
 			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, pg.hh, pg.wh, a.K, (int)(a.g.c * pg.plane_floats));
 		}
 		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
@@ -1033,32 +1063,47 @@ static bla_status launch_backward_pair(hipStream_t s, ConvArgs& w, ConvArgs& d, 
 
 template <bool RELU>
 static bla_status launch_group_norm(hipStream_t s, const float* in, float* out, float* stdevs, float* means, int channels, int group_size, int hw,
-                                    const unsigned char* drop, float* dropped) {
+                                    const unsigned char* drop, float* dropped, const PadOut* pad = nullptr) {
 	const int groups = (channels + group_size - 1) / group_size;
 	const long n_max = (long)(channels < group_size ? channels : group_size) * hw;
+	// pad: the padded copy of what feeds the next convolution (the dropped output when there is one, else the ReLU output) -- written by the 16-byte kernels in
+	// the same pass; the scalar forms do not carry it and a padding pass follows them
+	PadArgs pa = {};
+	bool pad_written = false;
+	if (pad && pad->dst) {
+		BLA_REQUIRE(pad->L.plane > 0 && pad->L.w > 0 && hw % pad->L.w == 0 && pad->L.w % 4 == 0, BLA_ERR_INVALID, "padded by-product: bad layout");
+		pa = PadArgs{pad->dst, hw, pad->L.w, pad->L.wh, pad->L.plane, pad->L.pt * pad->L.wh + pad->L.pl};
+	}
+	const bool vec = hw % 4 == 0 && ((uintptr_t)in | (uintptr_t)out | (uintptr_t)dropped) % 16 == 0 && (uintptr_t)drop % 4 == 0;
 	if (n_max <= kGnThreads * (kGnRegs / 2)) {   // (the one-workgroup kernel holds up to twice that in registers, but at 12 us against 9 sliced)
-		if (n_max <= kGnThreads * kGnVec * 4 && hw % 4 == 0 && ((uintptr_t)in | (uintptr_t)out | (uintptr_t)dropped) % 16 == 0 && (uintptr_t)drop % 4 == 0)
-			hipLaunchKernelGGL(group_norm_vec_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped);
-		else
-		hipLaunchKernelGGL(group_norm_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped);
+		if (n_max <= kGnThreads * kGnVec * 4 && vec) {
+			hipLaunchKernelGGL(group_norm_vec_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped, pa);
+			pad_written = true;
+		} else
+			hipLaunchKernelGGL(group_norm_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped);
 	} else {
 		const unsigned slices = (unsigned)((n_max + kGnSlice - 1) / kGnSlice);
 		BLA_REQUIRE(groups <= 65535, BLA_ERR_INVALID, "too many groups (%d)", groups);
 		void* ws;
 		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
 		if (st) return st;
-		const bool vec = hw % 4 == 0 && ((uintptr_t)in | (uintptr_t)out | (uintptr_t)dropped) % 16 == 0 && (uintptr_t)drop % 4 == 0;
 		if (vec) {
 			hipLaunchKernelGGL(group_norm_stats_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
 			hipLaunchKernelGGL((group_norm_apply_kernel<RELU, true>), dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
-			                   dropped, (const double2*)ws);
+			                   dropped, (const double2*)ws, pa);
+			pad_written = true;
 		} else {
 			hipLaunchKernelGGL(group_norm_stats_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, channels, group_size, hw, (double2*)ws);
 			hipLaunchKernelGGL((group_norm_apply_kernel<RELU, false>), dim3(slices, groups), dim3(kGnSliceThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop,
-			                   dropped, (const double2*)ws);
+			                   dropped, (const double2*)ws, PadArgs{});
 		}
 	}
 	BLA_HIP(hipGetLastError());
+	if (pa.dst && !pad_written) {   // rows of whole float4 are a precondition above, so this is the unaligned-pointer case only
+		const int h = hw / pad->L.w;
+		launch_pad_split(s, dropped ? dropped : out, pad->dst, (unsigned)channels, h, pad->L.w, pad->L.pt, pad->L.pl, 1, (unsigned)(pad->L.plane / pad->L.wh), (unsigned)pad->L.wh);
+		BLA_HIP(hipGetLastError());
+	}
 	return BLA_OK;
 }
 
@@ -1220,7 +1265,8 @@ __global__ void __launch_bounds__(kThreads) conv_epilogue_kernel(float* __restri
 }
 
 static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride,
-                                 const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr, int ep_bias_stride = 0) {
+                                 const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr, int ep_bias_stride = 0,
+                                 const float* x_padded = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -1235,6 +1281,7 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	if (st) return st;
 	a.A = d_kern; a.lda = k * k * c_in; a.img = d_x; a.out = d_out; a.ldo = gm.ho * gm.wo;
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
+	a.padded_src = x_padded;
 	const bool ep = ep_bias || ep_out2;
 	const FwdPlan plan = plan_forward(a, batch);
 	if (ep && !plan.fuses_epilogue) {
@@ -1403,7 +1450,7 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 }
 
 static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
-                                  float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride) {
+                                  float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -1456,6 +1503,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_del_y; a.lda = gm.ho * gm.wo; a.img = d_x; a.out = d_del_kern; a.ldo = k * k * c_in;
 		a.M = f_n; a.N = k * k * c_in; a.K = gm.ho * gm.wo;
+		a.padded_src = x_padded;
 		st = launch_implicit<CONV_WGRAD>(s, a, batch, x_sz, 0, y_sz);
 		if (st) return st;
 	}
@@ -1556,16 +1604,30 @@ bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_
 
 namespace bla {
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch, int ep_bias_stride) {
-	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch, int ep_bias_stride, const float* x_padded) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride, x_padded);
+}
+bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded) {
+	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride, x_padded);
+}
+// layout of the zero-padded copy a stride-1 convolution of this geometry gathers from (padded_geom / pad_split_kernel<1>): per plane hh rows of wh floats, the
+// image at (pt, pl); 0 = this geometry has no padded copy a producer could write (stride != 1, or rows that are no multiple of four pixels)
+PadLayout conv_padded_layout(int h, int w, int k, int stride) {
+	PadLayout L = {};
+	if (stride != 1 || w % 4 != 0) return L;
+	const Geometry gm = same_geometry(h, w, k, 1);
+	const PaddedGeom pg = padded_geom(ConvGeom{h, w, k, 1, 1, gm.ho, gm.wo, gm.pt, gm.pl});
+	L.w = w; L.wh = pg.wh; L.plane = (int)pg.plane_floats; L.pt = gm.pt; L.pl = gm.pl;
+	return L;
 }
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
-                                   int channels, int group_size, int hw) {
+                                   int channels, int group_size, int hw, const PadOut* pad) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
-	BLA_REQUIRE(d_in && d_relu && d_drop && d_dropped && d_stdevs && d_means, BLA_ERR_INVALID, "null operand");
-	return launch_group_norm<true>(pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw, d_drop, d_dropped);
+	BLA_REQUIRE(d_in && d_relu && d_stdevs && d_means && (d_drop == nullptr) == (d_dropped == nullptr) && (d_drop || pad), BLA_ERR_INVALID, "null operand");
+	return launch_group_norm<true>(pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw, d_drop, d_dropped, pad);
 }
 
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,

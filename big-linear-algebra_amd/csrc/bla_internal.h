@@ -56,8 +56,15 @@ bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const Gat
 
 // bla_conv.hip: implicit-GEMM convolution with the adds the U-Net puts behind it: out = conv + ep_bias[image * ep_bias_stride + channel];
 // ep_out2 = out + ep_add, both optional.  One image: folded into the store; a batch: one pass behind the product.
+// x_padded (batched callers): the zero-padded copy of d_x in conv_padded_layout(h, w, k, stride), written by the producer of d_x (the norm kernel in front):
+// the padded-copy forward / the weight gradient then make none of their own.  Ignored on the paths that use no padded copy.
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0, const float* x_padded = nullptr);
+bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded);
+struct PadLayout { int w, wh, plane, pt, pl; };      // plane = 0: none
+PadLayout conv_padded_layout(int h, int w, int k, int stride);
+struct PadOut { float* dst; PadLayout L; };          // a producer's second output: dst[plane_index * L.plane + (y + L.pt) * L.wh + x + L.pl], halo zeroed once by the owner
 
 // bla_conv_thin.hip: direct convolutions for at most four channels on one side (stride 1, k 1 or 3): forward with the optional epilogue, weight gradient
 bool thin_conv_applies(int k, int c_in, int f_n, int stride);
@@ -74,7 +81,7 @@ bla_status gemm_thin_parts(void* stream, int transa, int transb, int m, int n, i
 
 // group norm + ReLU + dropout in one pass (relu = max(norm, 0), dropped = drop ? 0 : relu), model/cifar_unet.c:1056-1058
 bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_relu, const unsigned char* d_drop, float* d_dropped, float* d_stdevs, float* d_means,
-                                   int channels, int group_size, int hw);
+                                   int channels, int group_size, int hw, const PadOut* pad = nullptr);   // d_drop may be NULL with pad (then the padded copy holds the ReLU output)
 // group_norm_ddx with the ReLU gate on its input and the residual gradient added to its output (either may be NULL), model/cifar_unet.c:1204-1205,1219
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
                                 int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend);
@@ -82,13 +89,16 @@ bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_de
 // bla_unet.hip: the batched ResNet block with the time-embedding projection hoisted out (bla_unet_model.hip forms all blocks' projections / time gradients in
 // one launch each): RESNET_TDENSE_READY = ws->tdense is already filled; RESNET_DEFER_TIME_GRADS = only the per-image channel sums go to d_dtb
 enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
+// padded copies of a block's two convolution inputs (relu1: B*cin planes, dp: B*cout planes; conv_padded_layout(h, w, k, 1); halo zeroed once by the owner):
+// the forward pass's norm kernels fill them and say so (have1 / have2), both convolutions and both weight gradients then gather from them
+struct ResnetPads { float* pad1; float* pad2; bool have1, have2; };
 bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
                                  float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
 bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
-                                  const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
+                                  const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags, ResnetPads* pads);
 bla_status resnet_backward_batched(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
                                    const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h, int w,
-                                   int cin, int cout, int k, int tdim, int group_size, int flags);
+                                   int cin, int cout, int k, int tdim, int group_size, int flags, const ResnetPads* pads);
 
 // "My gradients are ready", posted by the LAST gradient kernel of a data-parallel step instead of by the exchange launch behind it (every
 // step paid a launch boundary before any peer could start reading).  The block lives in device memory (built by bla_dp_connect); a launch that is

@@ -405,10 +405,16 @@ bla_status bla_resnet_backward_f32(void* stream, const float* d_del_out, const f
 /* The ResNet block for a batch: x / del_x [B][Cin][HW], result / del_out [B][Cout][HW], temb [B][T] (every image its own time step), d_drop
  * [B][Cout*HW]; the workspace buffers are B times the single-image sizes (tdense [B][Cout], mu / sd [B][groups]).  The convolutions run as
  * batched implicit GEMMs, the norms over B*C channels; the gradients are summed over the images.  d_dtb: [B][Cout] scratch. */
-static bla_status gn_relu_b(void* stream, int batch, const float* in, float* out, float* sd, float* mu, int c, int gs, int hw, const unsigned char* drop, float* dropped) {
+// pad (optional): the padded copy of what this norm feeds the next convolution with, written in the same pass; *pad_done says whether it was (only when the
+// batch folds into the channel count -- every shape of the U-Net does)
+static bla_status gn_relu_b(void* stream, int batch, const float* in, float* out, float* sd, float* mu, int c, int gs, int hw, const unsigned char* drop, float* dropped,
+                            const PadOut* pad = nullptr, bool* pad_done = nullptr) {
 	int ch, grp;
-	if (fold_groups(batch, c, gs, &ch, &grp))
+	if (pad_done) *pad_done = false;
+	if (fold_groups(batch, c, gs, &ch, &grp)) {
+		if (pad && pad->dst) { if (pad_done) *pad_done = true; return group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw, pad); }
 		return drop ? group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw) : bla_group_norm_relu_f32(stream, in, out, sd, mu, ch, grp, hw);
+	}
 	const int groups = (c + gs - 1) / gs;
 	for (int b = 0; b < batch; b++) {
 		const size_t o = (size_t)b * c * hw;
@@ -442,12 +448,12 @@ bla_status bla_group_norm_ddx_gated_batched_f32(void* stream, int batch, const f
 
 bla_status bla_resnet_forward_batched_f32(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
                                           const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size) {
-	return resnet_forward_batched(stream, batch, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, 0);
+	return resnet_forward_batched(stream, batch, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, 0, nullptr);
 }
 bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
                                            const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
                                            int w, int cin, int cout, int k, int tdim, int group_size) {
-	return resnet_backward_batched(stream, batch, d_del_out, d_x, d_temb, p, ws, g, sc, d_dtb, d_del_x, h, w, cin, cout, k, tdim, group_size, 0);
+	return resnet_backward_batched(stream, batch, d_del_out, d_x, d_temb, p, ws, g, sc, d_dtb, d_del_x, h, w, cin, cout, k, tdim, group_size, 0, nullptr);
 }
 
 }  // extern "C"
@@ -455,32 +461,40 @@ bla_status bla_resnet_backward_batched_f32(void* stream, int batch, const float*
 // flags (bla_internal.h): RESNET_TDENSE_READY -- ws->tdense already holds temb . W_t + b_t (the U-Net forms all 18 blocks' projections in one launch before the
 // first block); RESNET_DEFER_TIME_GRADS -- d_dtb receives the per-image channel sums and the caller forms time_w / time_b gradients from them later
 bla_status bla::resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,
-                                       const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags) {
+                                       const bla_resnet_ws* ws, float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags,
+                                       ResnetPads* pads) {
 	if (batch == 1) return resnet_forward_single(stream, d_x, d_temb, p, d_drop, ws, d_result, h, w, cin, cout, k, tdim, group_size, flags);
 	BLA_ENTER();
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
 	BLA_REQUIRE(d_x && d_temb && p && d_drop && ws && d_result && p->conv1 && p->conv2 && p->time_w && p->time_b, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && ws->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and workspace");
 	const int hw = h * w;
-	st = gn_relu_b(stream, batch, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw, nullptr, nullptr); if (st) return st;            // :1046-1047
+	// the norm kernels leave the padded copies their convolutions (and, later, the weight gradients) gather from: no padding pass of relu1 / dp anywhere
+	const PadLayout L = pads ? conv_padded_layout(h, w, k, 1) : PadLayout{};
+	const PadOut po1 = {pads && L.plane ? pads->pad1 : nullptr, L}, po2 = {pads && L.plane ? pads->pad2 : nullptr, L};
+	bool have1 = false, have2 = false;
+	st = gn_relu_b(stream, batch, d_x, ws->relu1, ws->sd1, ws->mu1, cin, group_size, hw, nullptr, nullptr, &po1, &have1); if (st) return st;            // :1046-1047
+	if (pads) { pads->have1 = have1; }
 	if (!(flags & RESNET_TDENSE_READY)) {
 		bla_gemm_epilogue ep = {};
 		ep.alpha = 1.f; ep.bias_col = p->time_b;
 		st = bla_gemm_f32(stream, 0, 0, batch, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st;      // :1051-1052, one row per image
 	}
-	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout); if (st) return st;   // :1048,1053
-	st = gn_relu_b(stream, batch, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw, d_drop, ws->dp); if (st) return st;          // :1056-1058
+	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout, have1 ? pads->pad1 : nullptr);
+	if (st) return st;                                                                                                                      // :1048,1053
+	st = gn_relu_b(stream, batch, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw, d_drop, ws->dp, &po2, &have2); if (st) return st;          // :1056-1058
+	if (pads) { pads->have2 = have2; }
 	const float* r = d_x;
 	if (cin != cout) {
 		st = bla_conv2d_forward_batched_f32(stream, d_x, p->res, ws->res, batch, h, w, 1, cin, cout, 1); if (st) return st;           // :1062-1066
 		r = ws->res;
 	}
-	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0);            // :1059,1067-1071
+	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0, have2 ? pads->pad2 : nullptr);   // :1059,1067-1071
 }
 
 bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
                                         const bla_resnet_ws* ws, const bla_resnet_grads* g, const bla_resnet_scratch* sc, float* d_dtb, float* d_del_x, int h,
-                                        int w, int cin, int cout, int k, int tdim, int group_size, int flags) {
+                                        int w, int cin, int cout, int k, int tdim, int group_size, int flags, const ResnetPads* pads) {
 	if (batch == 1 && d_del_x) return bla_resnet_backward_f32(stream, d_del_out, d_x, d_temb, p, ws, g, sc, d_del_x, h, w, cin, cout, k, tdim, group_size);
 	BLA_ENTER();
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && tdim > 0 && group_size > 0, BLA_ERR_INVALID, "bad resnet shape");
@@ -488,7 +502,8 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
 	const int hw = h * w;
-	st = bla_conv2d_backward_batched_f32(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1); if (st) return st;   // :1186-1189
+	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1, pads && pads->have2 ? pads->pad2 : nullptr);
+	if (st) return st;                                                                                                                      // :1186-1189
 	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
 	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
 	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
@@ -498,7 +513,8 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	}
 	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
 	// gradients and the last norm gradient are not formed, the weight gradients are
-	st = bla_conv2d_backward_batched_f32(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1);   // :1202-1205
+	st = conv2d_backward_batched(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
+	                             pads && pads->have1 ? pads->pad1 : nullptr);                                                               // :1202-1205
 	if (st) return st;
 	if (d_del_x) { st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st; }
 	if (cin != cout) {                                                                                                                  // :1208-1220

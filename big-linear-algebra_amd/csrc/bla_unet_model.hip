@@ -33,6 +33,7 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
+	ResnetPads pads = {nullptr, nullptr, false, false};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
 	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
@@ -125,7 +126,18 @@ bla_status alloc_res(bla_unet* m, Res& r) {
 		return st;
 	r.ws.res = nullptr;
 	if (r.cin != r.cout && (st = dalloc(m, &r.ws.res, r.cout * hw))) return st;
-	return m->batch > 1 ? dalloc(m, &r.dtb, (size_t)r.cout * m->batch) : BLA_OK;
+	if (m->batch == 1) return BLA_OK;
+	if ((st = dalloc(m, &r.dtb, (size_t)r.cout * m->batch))) return st;
+	// padded copies (conv_padded_layout): only where a tiled convolution will read them -- not for the 3-channel input of the first block (direct kernels)
+	static const bool pads_on = [] { const char* e = getenv("BLA_UNET_PADS"); return !(e && e[0] == '0'); }();
+	const PadLayout L = conv_padded_layout(r.h, r.w, m->cfg.kernel, 1);
+	if (pads_on && L.plane > 0) {
+		const size_t p1 = (size_t)m->batch * r.cin * L.plane, p2 = (size_t)m->batch * r.cout * L.plane;
+		if (r.cin > 4) { if ((st = dalloc(m, &r.pads.pad1, p1))) return st; BLA_HIP(hipMemsetAsync(r.pads.pad1, 0, p1 * sizeof(float), ctx().stream)); }
+		if ((st = dalloc(m, &r.pads.pad2, p2))) return st;
+		BLA_HIP(hipMemsetAsync(r.pads.pad2, 0, p2 * sizeof(float), ctx().stream));
+	}
+	return BLA_OK;
 }
 bla_status alloc_att_ws(bla_unet* m, bla_attention_ws& ws, size_t s1, size_t d) {
 	bla_status st;
@@ -380,7 +392,7 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		// the dropout decisions: block by block in forward order, inside a block image by image
 		return resnet_forward_batched(stream, B, in, d_time_embedding, &p, (d_drop ? d_drop : m->zero_drop) + r.drop_off * B, &r.ws, r.result, r.h, r.w, r.cin,
-		                              r.cout, c.kernel, c.time_dim, c.group_size, m->time_jobs ? RESNET_TDENSE_READY : 0);
+		                              r.cout, c.kernel, c.time_dim, c.group_size, m->time_jobs ? RESNET_TDENSE_READY : 0, B > 1 ? &r.pads : nullptr);
 	};
 	if (m->time_jobs) {   // every block's time-embedding projection depends on the embedding alone: one launch for the 18 of them
 		int max_cout = 0;
@@ -459,7 +471,7 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
 		return resnet_backward_batched(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, B > 1 ? r.dtb : m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim,
-		                               c.group_size, B > 1 ? RESNET_DEFER_TIME_GRADS : 0);
+		                               c.group_size, B > 1 ? RESNET_DEFER_TIME_GRADS : 0, B > 1 ? &r.pads : nullptr);
 	};
 	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Att& a = m->att[i];
