@@ -198,7 +198,9 @@ __device__ __forceinline__ void pad_store4(const PadArgs& pa, size_t e, float a,
 	const size_t pl = e / (unsigned)pa.hw;
 	const int pix = (int)(e - pl * (unsigned)pa.hw), y = pix / pa.w, x = pix - y * pa.w;
 	float* q = pa.dst + pl * (size_t)pa.plane + (size_t)y * pa.wh + x + pa.ptl;
-	q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+	q[0] = a; q[3] = d;
+	if (((uintptr_t)(q + 1) & 7) == 0) *reinterpret_cast<float2*>(q + 1) = make_float2(b, c);   // a one-pixel halo puts the middle pair on 8 bytes
+	else { q[1] = b; q[2] = c; }
 }
 template <bool RELU>
 __global__ void __launch_bounds__(kGnThreads) group_norm_vec_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ stdevs,
