@@ -546,6 +546,8 @@ struct ConvArgs {
 	// the caller already holds the zero-padded copy of `img` in this geometry's layout (conv_padded_layout: the norm kernel in front wrote it as a by-product):
 	// the padded-copy forward and the weight gradient read it instead of making their own
 	const float* padded_src = nullptr;
+	// the kernel matrix already in the form this product reads (conv_prepare_kernels: window order / flipped): no re-ordering launch in front
+	const float* prepared_A = nullptr;
 };
 
 __device__ __forceinline__ void conv_store(const ConvArgs& p, float* out, size_t image_off, int row, int col, float s) {
@@ -946,14 +948,18 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 	BLA_REQUIRE(!a.ep_fused_tiled || (plan.fuses_epilogue && plan.path != FWD_WSK), BLA_ERR_INVALID, "internal: a fused epilogue was planned for a path that has none");
 	if (MODE == CONV_FWD && plan.path == FWD_TILED_WINDOW) {
 		// straight from the image: the kernel matrix goes into the window kernel's contraction order in the workspace, then one product
-		void* ws;
-		bla_status st = ensure_workspace((size_t)a.M * a.K * sizeof(float) + 64, &ws);
-		if (st) return st;
-		if (a.flip_src) hipLaunchKernelGGL(window_order_flipped_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.flip_src, (float*)ws, a.M, a.g.c);
-		else hipLaunchKernelGGL(window_order_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, (float*)ws, a.M, a.g.c);
-		BLA_HIP(hipGetLastError());
+		const float* ordered = a.prepared_A;
+		if (!ordered) {
+			void* ws;
+			bla_status st = ensure_workspace((size_t)a.M * a.K * sizeof(float) + 64, &ws);
+			if (st) return st;
+			if (a.flip_src) hipLaunchKernelGGL(window_order_flipped_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.flip_src, (float*)ws, a.M, a.g.c);
+			else hipLaunchKernelGGL(window_order_kernels_kernel, dim3(grid_for((size_t)a.M * a.K)), dim3(kThreads), 0, s, a.A, (float*)ws, a.M, a.g.c);
+			BLA_HIP(hipGetLastError());
+			ordered = (const float*)ws;
+		}
 		const GatherEpilogue gep = {a.ep_bias, a.ep_bias_stride, a.ep_add, a.ep_out2};
-		return gather_gemm(s, 7, batch, a.M, a.N * batch, a.K, (const float*)ws, a.K, a.out, a.ldo, a.img, nullptr, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
+		return gather_gemm(s, 7, batch, a.M, a.N * batch, a.K, ordered, a.K, a.out, a.ldo, a.img, nullptr, nullptr, a.g.h, a.g.w, a.N, (int)img_stride,
 		                   a.ep_fused_tiled ? &gep : nullptr);
 	}
 	if (MODE == CONV_FWD ? plan.path != FWD_WSK : use_tiled_gather(a, batch, 2)) {
@@ -1268,7 +1274,7 @@ __global__ void __launch_bounds__(kThreads) conv_epilogue_kernel(float* __restri
 
 static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_kern, float* d_out, int batch, int h, int w, int k, int c_in, int f_n, int stride,
                                  const float* ep_bias = nullptr, const float* ep_add = nullptr, float* ep_out2 = nullptr, int ep_bias_stride = 0,
-                                 const float* x_padded = nullptr) {
+                                 const float* x_padded = nullptr, const float* prepared = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -1285,6 +1291,7 @@ static bla_status conv2d_forward(void* stream, const float* d_x, const float* d_
 	a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
 	a.padded_src = x_padded;
 	const bool ep = ep_bias || ep_out2;
+	if (prepared && plan_forward(a, batch).path == FWD_TILED_WINDOW) a.prepared_A = prepared;   // (mode 1 of conv_kernel_prep_mode: the only prepared form a forward pass takes)
 	const FwdPlan plan = plan_forward(a, batch);
 	if (ep && !plan.fuses_epilogue) {
 		// the half-slab forward kernels apply the adds where they store their tiles (one pass over K, whole tiles) and the 32x32 kernel does for a single
@@ -1452,7 +1459,8 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 }
 
 static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
-                                  float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded = nullptr) {
+                                  float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded = nullptr,
+                                  const float* prepared = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -1537,7 +1545,9 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
-		if (plan_forward(a, batch).path == FWD_TILED_WINDOW) a.flip_src = d_kern;      // flipped and window-ordered in one pass, inside launch_implicit
+		const bool window = plan_forward(a, batch).path == FWD_TILED_WINDOW;
+		if (prepared && stride == 1) { if (window) a.prepared_A = prepared; else a.A = prepared; }   // conv_kernel_prep_mode 2 / 3: already flipped (and window-ordered)
+		else if (window) a.flip_src = d_kern;      // flipped and window-ordered in one pass, inside launch_implicit
 		else {
 			hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
 			BLA_HIP(hipGetLastError());
@@ -1606,12 +1616,82 @@ bla_status bla_group_norm_ddx_f32(void* stream, const float* d_source, float* d_
 
 namespace bla {
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch, int ep_bias_stride, const float* x_padded) {
-	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride, x_padded);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch, int ep_bias_stride, const float* x_padded, const float* prepared) {
+	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride, x_padded, prepared);
 }
 bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
-                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded) {
-	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride, x_padded);
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared) {
+	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride, x_padded, prepared);
+}
+// Which prepared form (KernelPrepJob::mode) this convolution's forward / stride-1 data-gradient product reads; the same planning as conv2d_forward /
+// conv2d_backward (a 16-byte aligned kernel matrix is assumed: the U-Net's parameter bucket aligns every tensor)
+int conv_kernel_prep_mode(int batch, int h, int w, int k, int c_in, int f_n, int stride, bool data_gradient) {
+	if (batch < 2 || thin_conv_applies(k, c_in, f_n, stride) || !ctx().ready) return 0;
+	const Geometry gm = same_geometry(h, w, k, stride);
+	ConvArgs a;
+	a.A = reinterpret_cast<const float*>(uintptr_t(256));
+	if (!data_gradient) {
+		a.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
+		a.lda = k * k * c_in; a.M = f_n; a.N = gm.ho * gm.wo; a.K = k * k * c_in;
+		return plan_forward(a, batch).path == FWD_TILED_WINDOW ? 1 : 0;
+	}
+	if (stride != 1) return 0;                 // parity classes / zero dilation build their own sub-kernels
+	a.g = ConvGeom{h, w, k, f_n, 1, h, w, k - 1 - gm.pt, k - 1 - gm.pl};
+	a.lda = k * k * f_n; a.M = c_in; a.N = h * w; a.K = k * k * f_n;
+	// (conv2d_backward's one-launch pair for shapes that stay on the 32x32 kernel flips for itself: no prepared form there)
+	ConvArgs aw;
+	aw.g = ConvGeom{h, w, k, c_in, stride, gm.ho, gm.wo, gm.pt, gm.pl};
+	aw.A = a.A; aw.lda = gm.ho * gm.wo; aw.M = f_n; aw.N = k * k * c_in; aw.K = gm.ho * gm.wo;
+	if (!use_tiled_gather(aw, batch, 2) && !use_tiled_gather(a, batch, 1)) return 0;
+	return plan_forward(a, batch).path == FWD_TILED_WINDOW ? 2 : 3;
+}
+// Modes 2 and 3 transpose the (f, c) axes of [F][C][k*k]: read and written through a 16 x 16 tile of k*k-vectors in LDS so that both sides move whole
+// 16 * k*k-float runs (element by element the reads were 36-byte pieces a row apart: 49 us for the U-Net's 35 matrices).  Mode 1 only permutes inside a row.
+__global__ void __launch_bounds__(kThreads) prepare_kernels_kernel(const KernelPrepJob* __restrict__ jobs) {
+	const KernelPrepJob j = jobs[blockIdx.y];
+	const int kk = j.k * j.k;
+	if (j.mode == 1 || j.f_n % 16 || j.c_n % 16 || kk > 9) {
+		const int total = j.f_n * j.c_n * kk;
+		for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+			if (j.mode == 1) {          // window_order_kernels_kernel: rows f, contraction (g, t, c16)
+				const int kdim = j.c_n * 9, m = e / kdim, r = e - m * kdim, g = r / 144, q = r - g * 144, t = q >> 4, c16 = q & 15;
+				j.dst[e] = j.src[(size_t)m * kdim + (g * 16 + c16) * 9 + t];
+			} else if (j.mode == 2) {   // window_order_flipped_kernel: rows c, contraction (g, t, f16)
+				const int kdim = j.f_n * 9, m = e / kdim, r = e - m * kdim, g = r / 144, q = r - g * 144, t = q >> 4, f16 = q & 15;
+				j.dst[e] = j.src[((size_t)(g * 16 + f16) * j.c_n + m) * 9 + 8 - t];
+			} else {                    // flip_kernels_kernel
+				const int pq = e % kk, f = (e / kk) % j.f_n, c = e / (kk * j.f_n);
+				j.dst[e] = j.src[((size_t)f * j.c_n + c) * kk + kk - 1 - pq];
+			}
+		}
+		return;
+	}
+	__shared__ float tile[16][16 * 9 + 1];          // [f16][c16 * kk + pq]
+	const int tiles_c = j.c_n / 16, tiles = (j.f_n / 16) * tiles_c, run = 16 * kk;
+	for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+		const int f0 = (t / tiles_c) * 16, c0 = (t % tiles_c) * 16;
+		for (int e = threadIdx.x; e < 16 * run; e += kThreads) { const int f = e / run, r = e - f * run; tile[f][r] = j.src[((size_t)(f0 + f) * j.c_n + c0) * kk + r]; }
+		__syncthreads();
+		for (int e = threadIdx.x; e < 16 * run; e += kThreads) {
+			const int c = e / run, r = e - c * run;
+			if (j.mode == 3) {          // dst[c][f][pq] = src[f][c][kk - 1 - pq]
+				const int f = r / kk, pq = r - f * kk;
+				j.dst[((size_t)(c0 + c) * j.f_n + f0) * kk + r] = tile[f][c * kk + kk - 1 - pq];
+			} else {                    // dst[c][(g, t, f16)] = src[16 g + f16][c][8 - t]   (k = 3; g = f0 / 16)
+				const int tp = r >> 4, f = r & 15;
+				j.dst[(size_t)(c0 + c) * j.f_n * 9 + (size_t)(f0 / 16) * 144 + r] = tile[f][c * 9 + 8 - tp];
+			}
+		}
+		__syncthreads();
+	}
+}
+bla_status conv_prepare_kernels(void* stream, const KernelPrepJob* d_jobs, int njobs, size_t max_elements) {
+	if (njobs <= 0) return BLA_OK;
+	BLA_REQUIRE(d_jobs && njobs <= 65535, BLA_ERR_INVALID, "bad kernel preparation table");
+	const unsigned bx = (unsigned)std::min<size_t>(512, std::max<size_t>(1, max_elements / (16 * 16 * 9)));   // about one workgroup per 16 x 16 tile of the largest matrix
+	hipLaunchKernelGGL(prepare_kernels_kernel, dim3(bx, (unsigned)njobs), dim3(kThreads), 0, pick_stream(stream), d_jobs);
+	BLA_HIP(hipGetLastError());
+	return BLA_OK;
 }
 // layout of the zero-padded copy a stride-1 convolution of this geometry gathers from (padded_geom / pad_split_kernel<1>): per plane hh rows of wh floats, the
 // image at (pt, pl); 0 = this geometry has no padded copy a producer could write (stride != 1, or rows that are no multiple of four pixels)

@@ -59,9 +59,17 @@ bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const Gat
 // x_padded (batched callers): the zero-padded copy of d_x in conv_padded_layout(h, w, k, stride), written by the producer of d_x (the norm kernel in front):
 // the padded-copy forward / the weight gradient then make none of their own.  Ignored on the paths that use no padded copy.
 bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* d_kern, float* d_out, int h, int w, int k, int c_in, int f_n, int stride,
-                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0, const float* x_padded = nullptr);
+                                   const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0, const float* x_padded = nullptr,
+                                   const float* prepared = nullptr);
 bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
-                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded);
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared = nullptr);
+// Kernel matrices in the form a batched convolution's product reads them, prepared by the caller for MANY convolutions in one launch (the U-Net: once per
+// pass instead of a 5-us launch in front of every product): mode 1 = window order of the forward kernels (gather mode 7), 2 = flipped + window order (its
+// data gradient), 3 = flipped / transposed [C][F][k][k] (data gradient on the padded copy).  conv_kernel_prep_mode says which one a convolution's forward /
+// data-gradient product takes (0: none); conv2d_forward_epilogue / conv2d_backward_batched take the prepared matrix as `prepared`.
+struct KernelPrepJob { const float* src; float* dst; int f_n, c_n, k, mode; };
+int conv_kernel_prep_mode(int batch, int h, int w, int k, int c_in, int f_n, int stride, bool data_gradient);
+bla_status conv_prepare_kernels(void* stream, const KernelPrepJob* d_jobs, int njobs, size_t max_elements);
 struct PadLayout { int w, wh, plane, pt, pl; };      // plane = 0: none
 PadLayout conv_padded_layout(int h, int w, int k, int stride);
 struct PadOut { float* dst; PadLayout L; };          // a producer's second output: dst[plane_index * L.plane + (y + L.pt) * L.wh + x + L.pl], halo zeroed once by the owner
@@ -91,7 +99,8 @@ bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_de
 enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
 // padded copies of a block's two convolution inputs (relu1: B*cin planes, dp: B*cout planes; conv_padded_layout(h, w, k, 1); halo zeroed once by the owner):
 // the forward pass's norm kernels fill them and say so (have1 / have2), both convolutions and both weight gradients then gather from them
-struct ResnetPads { float* pad1; float* pad2; bool have1, have2; };
+struct ResnetPads { float* pad1; float* pad2; bool have1, have2;
+                    const float *k1_fwd, *k2_fwd, *k1_bwd, *k2_bwd; };   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
 bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
                                  float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
 bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,

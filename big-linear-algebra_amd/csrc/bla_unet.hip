@@ -480,7 +480,8 @@ bla_status bla::resnet_forward_batched(void* stream, int batch, const float* d_x
 		ep.alpha = 1.f; ep.bias_col = p->time_b;
 		st = bla_gemm_f32(stream, 0, 0, batch, cout, tdim, d_temb, tdim, p->time_w, cout, ws->tdense, cout, &ep); if (st) return st;      // :1051-1052, one row per image
 	}
-	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout, have1 ? pads->pad1 : nullptr);
+	st = conv2d_forward_epilogue(stream, ws->relu1, p->conv1, ws->c1, h, w, k, cin, cout, 1, ws->tdense, nullptr, nullptr, batch, cout, have1 ? pads->pad1 : nullptr,
+	                             pads ? pads->k1_fwd : nullptr);
 	if (st) return st;                                                                                                                      // :1048,1053
 	st = gn_relu_b(stream, batch, ws->c1, ws->relu2, ws->sd2, ws->mu2, cout, group_size, hw, d_drop, ws->dp, &po2, &have2); if (st) return st;          // :1056-1058
 	if (pads) { pads->have2 = have2; }
@@ -489,7 +490,8 @@ bla_status bla::resnet_forward_batched(void* stream, int batch, const float* d_x
 		st = bla_conv2d_forward_batched_f32(stream, d_x, p->res, ws->res, batch, h, w, 1, cin, cout, 1); if (st) return st;           // :1062-1066
 		r = ws->res;
 	}
-	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0, have2 ? pads->pad2 : nullptr);   // :1059,1067-1071
+	return conv2d_forward_epilogue(stream, ws->dp, p->conv2, ws->c2, h, w, k, cout, cout, 1, nullptr, r, d_result, batch, 0, have2 ? pads->pad2 : nullptr,
+	                               pads ? pads->k2_fwd : nullptr);                                                                          // :1059,1067-1071
 }
 
 bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_del_out, const float* d_x, const float* d_temb, const bla_resnet_params* p,
@@ -502,7 +504,8 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
 	const int hw = h * w;
-	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1, pads && pads->have2 ? pads->pad2 : nullptr);
+	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1, pads && pads->have2 ? pads->pad2 : nullptr,
+	                             pads ? pads->k2_bwd : nullptr);
 	if (st) return st;                                                                                                                      // :1186-1189
 	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
 	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
@@ -514,7 +517,7 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
 	// gradients and the last norm gradient are not formed, the weight gradients are
 	st = conv2d_backward_batched(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
-	                             pads && pads->have1 ? pads->pad1 : nullptr);                                                               // :1202-1205
+	                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr);                      // :1202-1205
 	if (st) return st;
 	if (d_del_x) { st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st; }
 	if (cin != cout) {                                                                                                                  // :1208-1220

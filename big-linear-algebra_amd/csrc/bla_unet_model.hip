@@ -33,7 +33,7 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
-	ResnetPads pads = {nullptr, nullptr, false, false};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
+	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
 	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
@@ -50,6 +50,7 @@ struct Conv {
 	size_t kern;
 	float* out;
 	bool present;
+	const float *prep_fwd = nullptr, *prep_bwd = nullptr;   // batched: the kernel matrix as the forward / data-gradient product reads it (KernelPrepJob outputs)
 };
 constexpr size_t kNone = (size_t)-1;
 }  // namespace
@@ -71,6 +72,9 @@ struct bla_unet {
 	// backward
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
 	TimeJob* time_jobs = nullptr;                // device, one per ResNet block (batch > 1)
+	KernelPrepJob *prep_fwd = nullptr, *prep_bwd = nullptr;   // device: every convolution's kernel matrix re-ordered / flipped in ONE launch per pass
+	int n_prep_fwd = 0, n_prep_bwd = 0;
+	size_t prep_max = 0;
 	float *dtb = nullptr, *partials = nullptr;   // batched blocks: per-image time-bias sums [B][Cout], per-image attention weight gradients [B][C*d]
 	bla_resnet_scratch sc = {};
 	bla_attention_ws agrad = {};
@@ -346,6 +350,46 @@ bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, i
 		m->time_jobs = (TimeJob*)tj;
 		BLA_HIP(hipMemcpy(tj, jobs, sizeof jobs, hipMemcpyHostToDevice));
 	}
+	static const bool prep_on = [] { const char* e = getenv("BLA_UNET_PREP"); return !(e && e[0] == '0'); }();
+	if (batch > 1 && prep_on) {
+		// One launch at the head of forward() and one at the head of backward() put every convolution's kernels into the form its product reads (window order,
+		// flipped): 49 five-microsecond launches per pass become 2.  The parameters do not change inside a pass, so the prepared copies are valid for it.
+		std::vector<KernelPrepJob> jf, jb;
+		auto add = [&](size_t kern_off, int h, int w, int k, int cin, int cout, int stride, bool want_dgrad, const float** pf, const float** pb) -> bla_status {
+			const size_t n = (size_t)cout * cin * k * k;
+			const int mf = conv_kernel_prep_mode(batch, h, w, k, cin, cout, stride, false), mb = want_dgrad ? conv_kernel_prep_mode(batch, h, w, k, cin, cout, stride, true) : 0;
+			for (int which = 0; which < 2; which++) {
+				const int mode = which ? mb : mf;
+				if (!mode) continue;
+				float* dst;
+				bla_status s2 = dalloc(m, &dst, n);
+				if (s2) return s2;
+				(which ? jb : jf).push_back(KernelPrepJob{m->params + kern_off, dst, cout, cin, k, mode});
+				*(which ? pb : pf) = dst;
+				m->prep_max = std::max(m->prep_max, n);
+			}
+			return BLA_OK;
+		};
+		for (int i = 0; i < 18; i++) {
+			Res& r = m->res[i];
+			if ((st = add(r.conv1, r.h, r.w, cfg->kernel, r.cin, r.cout, 1, i != 0, &r.pads.k1_fwd, &r.pads.k1_bwd)) ||     // (block 0 forms no gradient of the image)
+			    (st = add(r.conv2, r.h, r.w, cfg->kernel, r.cout, r.cout, 1, true, &r.pads.k2_fwd, &r.pads.k2_bwd)))
+				return fail(st);
+		}
+		for (int i = 0; i < 3; i++)
+			if (m->up[i].present && (st = add(m->up[i].kern, m->up[i].h, m->up[i].w, m->up[i].k, m->up[i].cin, m->up[i].cout, 1, true, &m->up[i].prep_fwd, &m->up[i].prep_bwd))) return fail(st);
+		auto upload = [&](const std::vector<KernelPrepJob>& v, KernelPrepJob** d, int* n) -> bla_status {
+			*n = (int)v.size();
+			if (v.empty()) return BLA_OK;
+			void* q = nullptr;
+			BLA_HIP(hipMalloc(&q, v.size() * sizeof(KernelPrepJob)));
+			m->owned.push_back(q);
+			BLA_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(KernelPrepJob), hipMemcpyHostToDevice));
+			*d = (KernelPrepJob*)q;
+			return BLA_OK;
+		};
+		if ((st = upload(jf, &m->prep_fwd, &m->n_prep_fwd)) || (st = upload(jb, &m->prep_bwd, &m->n_prep_bwd))) return fail(st);
+	}
 	BLA_HIP(hipStreamSynchronize(ctx().stream));
 	*out = m;
 	return BLA_OK;
@@ -406,8 +450,9 @@ bla_status bla_unet_forward_f32(bla_unet* m, void* stream, const float* d_x, con
 		return bla_attention_forward_batched_f32(stream, B, in, P + a.wq, P + a.wk, P + a.wv, P + a.wo, P + a.bias, &a.fwd, a.out, a.c, a.h * a.w, c.key_dim);
 	};
 	auto conv = [&](Conv& k, const float* in) -> bla_status {
-		return bla_conv2d_forward_batched_f32(stream, in, P + k.kern, k.out, B, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+		return conv2d_forward_epilogue(stream, in, P + k.kern, k.out, k.h, k.w, k.k, k.cin, k.cout, k.stride, nullptr, nullptr, nullptr, B, 0, nullptr, k.prep_fwd);
 	};
+	if (m->n_prep_fwd) { st = conv_prepare_kernels(stream, m->prep_fwd, m->n_prep_fwd, m->prep_max); if (st) return st; }
 	auto concat = [&](int stage, const float* a, const float* skip, size_t n) -> bla_status {   // _concat_skip, :1088-1097 (n: floats per image and half)
 		if (n % 4 == 0 && ((uintptr_t)a | (uintptr_t)skip | (uintptr_t)m->cat[stage]) % 16 == 0)
 			hipLaunchKernelGGL(unet_concat4_kernel, dim3(grid_of(n / 2 * B)), dim3(256), 0, s, (const float4*)a, (const float4*)skip, (float4*)m->cat[stage], n / 4, n / 2 * B);
@@ -479,8 +524,9 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		                                          G + a.wo, out, a.c, a.h * a.w, c.key_dim, 0);
 	};
 	auto conv = [&](Conv& k, const float* g, const float* x, float* out) -> bla_status {
-		return bla_conv2d_backward_batched_f32(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride);
+		return conv2d_backward_batched(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride, nullptr, k.prep_bwd);
 	};
+	if (m->n_prep_bwd) { st = conv_prepare_kernels(stream, m->prep_bwd, m->n_prep_bwd, m->prep_max); if (st) return st; }
 	// up-sampling stage i backwards: gradient of (the optional convolution's output | the resized map) -> gradient of the map before resizing;
 	// g, tmp and out are three different buffers
 	auto upsample = [&](int i, const float* g, float* tmp, float* out) -> bla_status {
