@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_vec_kernel(const float*
 		float y[4] = {(v[i].x - mean) / var, (v[i].y - mean) / var, (v[i].z - mean) / var, (v[i].w - mean) / var};   // (x - mean) / (stdev + 0), lib/norm.c:44
 #pragma unroll
 		for (int e = 0; e < 4; e++) y[e] = RELU && y[e] < 0.f ? 0.f : y[e];
-		reinterpret_cast<float4*>(out + off)[j] = make_float4(y[0], y[1], y[2], y[3]);
+		if (out) reinterpret_cast<float4*>(out + off)[j] = make_float4(y[0], y[1], y[2], y[3]);   // (out == NULL: only the dropped form is kept)
 		if (dropped) {
 			const uchar4 d = reinterpret_cast<const uchar4*>(drop + off)[j];
 			if (d.x) y[0] = 0.f;
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_apply_kernel(const
 			float y[4] = {(v.x - mean) / var, (v.y - mean) / var, (v.z - mean) / var, (v.w - mean) / var};
 #pragma unroll
 			for (int e = 0; e < 4; e++) y[e] = RELU && y[e] < 0.f ? 0.f : y[e];
-			*reinterpret_cast<float4*>(out + off + i) = make_float4(y[0], y[1], y[2], y[3]);
+			if (out) *reinterpret_cast<float4*>(out + off + i) = make_float4(y[0], y[1], y[2], y[3]);
 			if (dropped) {
 				const uchar4 d = *reinterpret_cast<const uchar4*>(drop + off + i);
 				if (d.x) y[0] = 0.f;
@@ -1083,6 +1083,8 @@ static bla_status launch_group_norm(hipStream_t s, const float* in, float* out, 
 		pa = PadArgs{pad->dst, hw, pad->L.w, pad->L.wh, pad->L.plane, pad->L.pt * pad->L.wh + pad->L.pl};
 	}
 	const bool vec = hw % 4 == 0 && ((uintptr_t)in | (uintptr_t)out | (uintptr_t)dropped) % 16 == 0 && (uintptr_t)drop % 4 == 0;
+	// out == NULL (the caller keeps only the dropped form: the backward pass gates on it alone): the 16-byte kernels take that, the scalar ones do not
+	BLA_REQUIRE(out || (dropped && vec && (n_max > kGnThreads * (kGnRegs / 2) || n_max <= kGnThreads * kGnVec * 4)), BLA_ERR_INVALID, "group norm without its plain output needs the 16-byte kernels");
 	if (n_max <= kGnThreads * (kGnRegs / 2)) {   // (the one-workgroup kernel holds up to twice that in registers, but at 12 us against 9 sliced)
 		if (n_max <= kGnThreads * kGnVec * 4 && vec) {
 			hipLaunchKernelGGL(group_norm_vec_kernel<RELU>, dim3(groups), dim3(kGnThreads), 0, s, in, out, stdevs, means, channels, group_size, hw, drop, dropped, pa);
@@ -1708,7 +1710,7 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
-	BLA_REQUIRE(d_in && d_relu && d_stdevs && d_means && (d_drop == nullptr) == (d_dropped == nullptr) && (d_drop || pad), BLA_ERR_INVALID, "null operand");
+	BLA_REQUIRE(d_in && (d_relu || d_dropped) && d_stdevs && d_means && (d_drop == nullptr) == (d_dropped == nullptr) && (d_drop || pad), BLA_ERR_INVALID, "null operand");
 	return launch_group_norm<true>(pick_stream(stream), d_in, d_relu, d_stdevs, d_means, channels, group_size, hw, d_drop, d_dropped, pad);
 }
 

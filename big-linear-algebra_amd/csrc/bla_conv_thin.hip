@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) thin_wgrad_fold_kernel(const float* __res
 
 bool thin_conv_applies(int k, int c_in, int f_n, int stride) {
 	static const bool enabled = [] { const char* v = getenv("BLA_CONV_THIN"); return !(v && v[0] == '0'); }();
-	return enabled && stride == 1 && (k == 1 || k == 3) && (c_in <= kMaxThin || f_n <= kMaxThin) && c_in <= 4096 / (k * k);
+	return enabled && stride == 1 && (k == 1 || k == 3) && (c_in <= kMaxThin || (f_n <= kMaxThin && c_in * k * k <= 3584));   // (the few-outputs form keeps 4 x C x k x k kernels in LDS: 60 KB at most)
 }
 
 // out [B][F][H][W] = conv(x [B][C][H][W], kern [F][C][k][k]) with pads (pt, pl) on the top / left (stride 1, output H x W); optional epilogue

@@ -412,7 +412,7 @@ static bla_status gn_relu_b(void* stream, int batch, const float* in, float* out
 	int ch, grp;
 	if (pad_done) *pad_done = false;
 	if (fold_groups(batch, c, gs, &ch, &grp)) {
-		if (pad && pad->dst) { if (pad_done) *pad_done = true; return group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw, pad); }
+		if ((pad && pad->dst) || !out) { if (pad_done) *pad_done = pad && pad->dst; return group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw, pad); }
 		return drop ? group_norm_relu_dropout(stream, in, out, drop, dropped, sd, mu, ch, grp, hw) : bla_group_norm_relu_f32(stream, in, out, sd, mu, ch, grp, hw);
 	}
 	const int groups = (c + gs - 1) / gs;

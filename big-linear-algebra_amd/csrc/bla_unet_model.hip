@@ -120,12 +120,19 @@ void plan_conv(bla_unet* m, Conv& c, const std::string& name, int cin, int cout,
 	c.cin = cin; c.cout = cout; c.h = h; c.w = w; c.stride = stride; c.k = m->cfg.kernel; c.present = present; c.out = nullptr;
 	c.kern = present ? add_tensor(m, name, (size_t)cout * cin * c.k * c.k) : kNone;
 }
+// The second ReLU's output before dropout: the backward pass gates on the dropped form alone (dp = drop ? 0 : relu2 is zero wherever relu2 is), so a batched
+// model whose norms run on the 16-byte kernels (rows of whole float4, a batch that folds into the channel count) does not store it
+bool keep_relu2(const bla_unet* m, const Res& r) {
+	const int gs = m->cfg.group_size;
+	return !(m->batch > 1 && (r.h * r.w) % 4 == 0 && (r.cout % gs == 0 || r.cout < gs));
+}
 bla_status alloc_res(bla_unet* m, Res& r) {
 	const size_t hw = (size_t)r.h * r.w * m->batch;   // (every buffer of the block: B times its single-image size)
 	const int gs = m->cfg.group_size, g1 = (r.cin + gs - 1) / gs * m->batch, g2 = (r.cout + gs - 1) / gs * m->batch;
 	bla_status st;
 	if ((st = dalloc(m, &r.ws.mu1, g1)) || (st = dalloc(m, &r.ws.sd1, g1)) || (st = dalloc(m, &r.ws.relu1, r.cin * hw)) || (st = dalloc(m, &r.ws.c1, r.cout * hw)) ||
-	    (st = dalloc(m, &r.ws.tdense, (size_t)r.cout * m->batch)) || (st = dalloc(m, &r.ws.mu2, g2)) || (st = dalloc(m, &r.ws.sd2, g2)) || (st = dalloc(m, &r.ws.relu2, r.cout * hw)) ||
+	    (st = dalloc(m, &r.ws.tdense, (size_t)r.cout * m->batch)) || (st = dalloc(m, &r.ws.mu2, g2)) || (st = dalloc(m, &r.ws.sd2, g2)) ||
+	    (keep_relu2(m, r) ? (st = dalloc(m, &r.ws.relu2, r.cout * hw)) : (r.ws.relu2 = nullptr, BLA_OK)) ||
 	    (st = dalloc(m, &r.ws.dp, r.cout * hw)) || (st = dalloc(m, &r.ws.c2, r.cout * hw)) || (st = dalloc(m, &r.result, r.cout * hw)))
 		return st;
 	r.ws.res = nullptr;
@@ -168,7 +175,8 @@ __global__ void __launch_bounds__(256) time_dense_all_kernel(const TimeJob* __re
 	const int per = (tdim + 3) / 4, t0 = quarter * per, t1 = min(tdim, t0 + per);
 	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	if (c < j.cout)
-		for (int t = t0; t < t1; t++) {
+#pragma unroll 8
+		for (int t = t0; t < t1; t++) {      // (eight weight loads in flight: one by one this loop is 128 dependent round trips, 53 us)
 			const float wv = j.w[(size_t)t * j.cout + c];
 #pragma unroll
 			for (int i = 0; i < 8; i++) acc[i] = fmaf(te[i * tdim + t], wv, acc[i]);
@@ -188,6 +196,7 @@ __global__ void __launch_bounds__(256) time_grads_all_kernel(const TimeJob* __re
 	const int t0 = blockIdx.y * 8, nt = min(8, tdim - t0);
 	for (int c = threadIdx.x; c < j.cout; c += 256) {
 		float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+#pragma unroll 8
 		for (int b = 0; b < batch; b++) {
 			const float d = j.dtb[(size_t)b * j.cout + c];
 			sb += d;
@@ -338,7 +347,7 @@ bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, i
 	m->owned.push_back(z);
 	m->zero_drop = (unsigned char*)z;
 	BLA_HIP(hipMemsetAsync(z, 0, zero_bytes, ctx().stream));
-	{   // the 18 time-embedding projections (and, for a batch, their gradients) as one launch each way: the jobs' addresses are fixed from here on
+	if (cfg->time_dim <= 1024) {   // the 18 time-embedding projections (and, for a batch, their gradients) as one launch each way (eight embedding rows in LDS): the jobs' addresses are fixed from here on
 		TimeJob jobs[18];
 		for (int i = 0; i < 18; i++) {
 			const Res& r = m->res[i];
@@ -516,7 +525,7 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
 		return resnet_backward_batched(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, B > 1 ? r.dtb : m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim,
-		                               c.group_size, B > 1 ? RESNET_DEFER_TIME_GRADS : 0, B > 1 ? &r.pads : nullptr);
+		                               c.group_size, B > 1 && m->time_jobs ? RESNET_DEFER_TIME_GRADS : 0, B > 1 ? &r.pads : nullptr);
 	};
 	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Att& a = m->att[i];
@@ -587,7 +596,7 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 	TRY(bla_add_f32(stream, a, m->gskip[3], n0 * B));
 	TRY(res(1, a, m->res[0].result, b));
 	TRY(res(0, b, m->last_x, nullptr));   // nothing consumes the gradient of the image: the first block forms its weight gradients only
-	if (B > 1) {   // the 18 blocks' time-weight / time-bias gradients from the channel sums each block left behind (:1191-1199)
+	if (B > 1 && m->time_jobs) {   // the 18 blocks' time-weight / time-bias gradients from the channel sums each block left behind (:1191-1199)
 		hipLaunchKernelGGL(time_grads_all_kernel, dim3(18, (unsigned)((c.time_dim + 7) / 8)), dim3(256), 0, s, m->time_jobs, temb, B, c.time_dim);
 		BLA_HIP(hipGetLastError());
 	}
