@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_vec_kernel(const float*
 }
 __global__ void __launch_bounds__(kGnThreads) group_norm_ddx_vec_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
                                                                          const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
-                                                                         int group_size, int hw, const float* __restrict__ relu_gate, const float* __restrict__ addend) {
+                                                                         int group_size, int hw, const float* __restrict__ relu_gate, const float* __restrict__ addend, PadArgs pa) {
 	const int g = blockIdx.x, t = threadIdx.x;
 	const int nch = min(group_size, channels - g * group_size);
 	const size_t off = (size_t)g * group_size * hw;
@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(kGnThreads) group_norm_ddx_vec_kernel(const fl
 		for (int e = 0; e < 4; e++) r[e] = (sv[i][e] - fgs - nv[i][e] * fgws) / sd;
 		if (addend) { const float4 a = reinterpret_cast<const float4*>(addend + off)[j]; r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w; }
 		reinterpret_cast<float4*>(dest + off)[j] = make_float4(r[0], r[1], r[2], r[3]);
+		if (pa.dst) pad_store4(pa, off + 4 * (size_t)j, r[0], r[1], r[2], r[3]);
 	}
 }
 
@@ -464,7 +465,7 @@ template <bool VEC>
 __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_apply_kernel(const float* __restrict__ source, float* __restrict__ dest, const float* __restrict__ data,
                                                                                 const float* __restrict__ means, const float* __restrict__ stdevs, int channels,
                                                                                 int group_size, int hw, const float* __restrict__ relu_gate,
-                                                                                const float* __restrict__ addend, const double2* __restrict__ partials) {
+                                                                                const float* __restrict__ addend, const double2* __restrict__ partials, PadArgs pa) {
 	const int g = blockIdx.y, slice = blockIdx.x;
 	const int nch = min(group_size, channels - g * group_size);
 	const size_t off = (size_t)g * group_size * hw;
@@ -489,6 +490,7 @@ __global__ void __launch_bounds__(kGnSliceThreads) group_norm_ddx_apply_kernel(c
 				r[e] = addend ? d + aa[e] : d;
 			}
 			*reinterpret_cast<float4*>(dest + off + i) = make_float4(r[0], r[1], r[2], r[3]);
+			if (pa.dst) pad_store4(pa, off + (size_t)i, r[0], r[1], r[2], r[3]);
 		}
 		return;
 	}
@@ -1118,34 +1120,46 @@ static bla_status launch_group_norm(hipStream_t s, const float* in, float* out, 
 }
 
 static bla_status launch_group_norm_ddx(hipStream_t s, const float* source, float* dest, const float* data, const float* means, const float* stdevs, int channels,
-                                        int group_size, int hw, const float* relu_gate, const float* addend) {
+                                        int group_size, int hw, const float* relu_gate, const float* addend, const PadOut* pad = nullptr) {
 	const int groups = (channels + group_size - 1) / group_size;
 	const long n_max = (long)(channels < group_size ? channels : group_size) * hw;
+	PadArgs pa = {};       // the gradient again, inside the zero-padded copy the data-gradient convolution behind it gathers from (as launch_group_norm)
+	bool pad_written = false;
+	if (pad && pad->dst) {
+		BLA_REQUIRE(pad->L.plane > 0 && pad->L.w > 0 && hw % pad->L.w == 0 && pad->L.w % 4 == 0, BLA_ERR_INVALID, "padded by-product: bad layout");
+		pa = PadArgs{pad->dst, hw, pad->L.w, pad->L.wh, pad->L.plane, pad->L.pt * pad->L.wh + pad->L.pl};
+	}
+	const bool vec = hw % 4 == 0 && ((uintptr_t)source | (uintptr_t)dest | (uintptr_t)data | (uintptr_t)relu_gate | (uintptr_t)addend) % 16 == 0;
 	if (n_max <= kGnThreads * (kGnRegs / 2)) {
-		if (n_max <= kGnThreads * kGnVec * 4 && hw % 4 == 0 && ((uintptr_t)source | (uintptr_t)dest | (uintptr_t)data | (uintptr_t)relu_gate | (uintptr_t)addend) % 16 == 0)
-			hipLaunchKernelGGL(group_norm_ddx_vec_kernel, dim3(groups), dim3(kGnThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw, relu_gate, addend);
-		else
-		hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kGnThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw, relu_gate, addend);
+		if (n_max <= kGnThreads * kGnVec * 4 && vec) {
+			hipLaunchKernelGGL(group_norm_ddx_vec_kernel, dim3(groups), dim3(kGnThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw, relu_gate, addend, pa);
+			pad_written = true;
+		} else
+			hipLaunchKernelGGL(group_norm_ddx_kernel, dim3(groups), dim3(kGnThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw, relu_gate, addend);
 	} else {
 		const unsigned slices = (unsigned)((n_max + kGnSlice - 1) / kGnSlice);
 		BLA_REQUIRE(groups <= 65535, BLA_ERR_INVALID, "too many groups (%d)", groups);
 		void* ws;
 		bla_status st = ensure_workspace((size_t)groups * slices * sizeof(double2), &ws);
 		if (st) return st;
-		const bool vec = hw % 4 == 0 && ((uintptr_t)source | (uintptr_t)dest | (uintptr_t)data | (uintptr_t)relu_gate | (uintptr_t)addend) % 16 == 0;
 		if (vec) {
 			hipLaunchKernelGGL(group_norm_ddx_stats_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
 			                   relu_gate, (double2*)ws);
 			hipLaunchKernelGGL(group_norm_ddx_apply_kernel<true>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
-			                   relu_gate, addend, (const double2*)ws);
+			                   relu_gate, addend, (const double2*)ws, pa);
+			pad_written = true;
 		} else {
 			hipLaunchKernelGGL(group_norm_ddx_stats_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, data, means, stdevs, channels, group_size, hw,
 			                   relu_gate, (double2*)ws);
 			hipLaunchKernelGGL(group_norm_ddx_apply_kernel<false>, dim3(slices, groups), dim3(kGnSliceThreads), 0, s, source, dest, data, means, stdevs, channels, group_size, hw,
-			                   relu_gate, addend, (const double2*)ws);
+			                   relu_gate, addend, (const double2*)ws, PadArgs{});
 		}
 	}
 	BLA_HIP(hipGetLastError());
+	if (pa.dst && !pad_written) {
+		launch_pad_split(s, dest, pad->dst, (unsigned)channels, hw / pad->L.w, pad->L.w, pad->L.pt, pad->L.pl, 1, (unsigned)(pad->L.plane / pad->L.wh), (unsigned)pad->L.wh);
+		BLA_HIP(hipGetLastError());
+	}
 	return BLA_OK;
 }
 
@@ -1462,7 +1476,7 @@ static bla_status conv2d_backward_parity(hipStream_t s, const float* d_del_y, co
 
 static bla_status conv2d_backward(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x,
                                   float* d_scratch, int batch, int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded = nullptr,
-                                  const float* prepared = nullptr) {
+                                  const float* prepared = nullptr, const float* dy_padded = nullptr) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && c_in > 0 && f_n > 0 && stride > 0, BLA_ERR_INVALID, "bad conv shape");
@@ -1547,6 +1561,7 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		if (st) return st;
 		a.A = d_scratch; a.lda = k * k * f_n; a.img = src; a.out = d_del_x; a.ldo = h * w;
 		a.M = c_in; a.N = h * w; a.K = k * k * f_n;
+		if (stride == 1 && k % 2 == 1) a.padded_src = dy_padded;   // (odd k: the mirrored pads are the forward's, so the copy has conv_padded_layout(h, w, k, 1))
 		const bool window = plan_forward(a, batch).path == FWD_TILED_WINDOW;
 		if (prepared && stride == 1) { if (window) a.prepared_A = prepared; else a.A = prepared; }   // conv_kernel_prep_mode 2 / 3: already flipped (and window-ordered)
 		else if (window) a.flip_src = d_kern;      // flipped and window-ordered in one pass, inside launch_implicit
@@ -1622,8 +1637,8 @@ bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* 
 	return conv2d_forward(stream, d_x, d_kern, d_out, batch, h, w, k, c_in, f_n, stride, ep_bias, ep_add, ep_out2, ep_bias_stride, x_padded, prepared);
 }
 bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
-                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared) {
-	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride, x_padded, prepared);
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared, const float* dy_padded) {
+	return conv2d_backward(stream, d_del_y, d_x, d_kern, d_del_kern, d_del_x, d_scratch, batch, h, w, k, c_in, f_n, stride, x_padded, prepared, dy_padded);
 }
 // Which prepared form (KernelPrepJob::mode) this convolution's forward / stride-1 data-gradient product reads; the same planning as conv2d_forward /
 // conv2d_backward (a 16-byte aligned kernel matrix is assumed: the U-Net's parameter bucket aligns every tensor)
@@ -1715,11 +1730,11 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
 }
 
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
-                                int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend) {
+                                int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend, const PadOut* pad) {
 	bla_status st = require_ready();
 	if (st) return st;
 	BLA_REQUIRE(channels > 0 && group_size > 0 && hw > 0, BLA_ERR_INVALID, "bad group_norm shape channels=%d group=%d hw=%d", channels, group_size, hw);
 	BLA_REQUIRE(d_source && d_dest && d_data && d_means && d_stdevs, BLA_ERR_INVALID, "null operand");
-	return launch_group_norm_ddx(pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels, group_size, hw, d_relu_gate, d_addend);
+	return launch_group_norm_ddx(pick_stream(stream), d_source, d_dest, d_data, d_means, d_stdevs, channels, group_size, hw, d_relu_gate, d_addend, pad);
 }
 }  // namespace bla

@@ -62,7 +62,8 @@ bla_status conv2d_forward_epilogue(void* stream, const float* d_x, const float* 
                                    const float* ep_bias, const float* ep_add, float* ep_out2, int batch = 1, int ep_bias_stride = 0, const float* x_padded = nullptr,
                                    const float* prepared = nullptr);
 bla_status conv2d_backward_batched(void* stream, const float* d_del_y, const float* d_x, const float* d_kern, float* d_del_kern, float* d_del_x, float* d_scratch, int batch,
-                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared = nullptr);
+                                   int h, int w, int k, int c_in, int f_n, int stride, const float* x_padded, const float* prepared = nullptr,
+                                   const float* dy_padded = nullptr);   // dy_padded: the same for d_del_y (odd k, stride 1: the padded-copy data gradient reads it)
 // Kernel matrices in the form a batched convolution's product reads them, prepared by the caller for MANY convolutions in one launch (the U-Net: once per
 // pass instead of a 5-us launch in front of every product): mode 1 = window order of the forward kernels (gather mode 7), 2 = flipped + window order (its
 // data gradient), 3 = flipped / transposed [C][F][k][k] (data gradient on the padded copy).  conv_kernel_prep_mode says which one a convolution's forward /
@@ -92,7 +93,7 @@ bla_status group_norm_relu_dropout(void* stream, const float* d_in, float* d_rel
                                    int channels, int group_size, int hw, const PadOut* pad = nullptr);   // d_drop may be NULL with pad (then the padded copy holds the ReLU output)
 // group_norm_ddx with the ReLU gate on its input and the residual gradient added to its output (either may be NULL), model/cifar_unet.c:1204-1205,1219
 bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_dest, const float* d_data, const float* d_means, const float* d_stdevs,
-                                int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend);
+                                int channels, int group_size, int hw, const float* d_relu_gate, const float* d_addend, const PadOut* pad = nullptr);
 
 // bla_unet.hip: the batched ResNet block with the time-embedding projection hoisted out (bla_unet_model.hip forms all blocks' projections / time gradients in
 // one launch each): RESNET_TDENSE_READY = ws->tdense is already filled; RESNET_DEFER_TIME_GRADS = only the per-image channel sums go to d_dtb
@@ -100,7 +101,8 @@ enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
 // padded copies of a block's two convolution inputs (relu1: B*cin planes, dp: B*cout planes; conv_padded_layout(h, w, k, 1); halo zeroed once by the owner):
 // the forward pass's norm kernels fill them and say so (have1 / have2), both convolutions and both weight gradients then gather from them
 struct ResnetPads { float* pad1; float* pad2; bool have1, have2;
-                    const float *k1_fwd, *k2_fwd, *k1_bwd, *k2_bwd; };   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
+                    const float *k1_fwd, *k2_fwd, *k1_bwd, *k2_bwd;
+                    float* dy_pad; };   // scratch of the block's resolution (B*cout planes, halo zeroed once): the padded gradient the first convolution's data gradient reads   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
 bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
                                  float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
 bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,

@@ -425,9 +425,13 @@ static bla_status gn_relu_b(void* stream, int batch, const float* in, float* out
 	return BLA_OK;
 }
 static bla_status gn_ddx_b(void* stream, int batch, const float* src, float* dst, const float* data, const float* mu, const float* sd, int c, int gs, int hw,
-                           const float* gate, const float* addend) {
+                           const float* gate, const float* addend, const PadOut* pad = nullptr, bool* pad_done = nullptr) {
 	int ch, grp;
-	if (fold_groups(batch, c, gs, &ch, &grp)) return group_norm_ddx_gated(stream, src, dst, data, mu, sd, ch, grp, hw, gate, addend);
+	if (pad_done) *pad_done = false;
+	if (fold_groups(batch, c, gs, &ch, &grp)) {
+		if (pad && pad->dst && pad_done) *pad_done = true;
+		return group_norm_ddx_gated(stream, src, dst, data, mu, sd, ch, grp, hw, gate, addend, pad);
+	}
 	const int groups = (c + gs - 1) / gs;
 	for (int b = 0; b < batch; b++) {
 		const size_t o = (size_t)b * c * hw;
@@ -507,7 +511,12 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1, pads && pads->have2 ? pads->pad2 : nullptr,
 	                             pads ? pads->k2_bwd : nullptr);
 	if (st) return st;                                                                                                                      // :1186-1189
-	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr); if (st) return st;
+	// the gradient that reaches the first convolution also lands in the padded copy its data gradient gathers from -- where that product runs on the padded-copy
+	// kernel (prep mode 3) and someone wants it
+	const PadLayout L = pads && pads->dy_pad && d_del_x && k % 2 == 1 && conv_kernel_prep_mode(batch, h, w, k, cin, cout, 1, true) == 3 ? conv_padded_layout(h, w, k, 1) : PadLayout{};
+	const PadOut pod = {L.plane ? pads->dy_pad : nullptr, L};
+	bool have_dy = false;
+	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr, &pod, &have_dy); if (st) return st;
 	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
 	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
 	if (!(flags & RESNET_DEFER_TIME_GRADS)) {
@@ -517,7 +526,7 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
 	// gradients and the last norm gradient are not formed, the weight gradients are
 	st = conv2d_backward_batched(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
-	                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr);                      // :1202-1205
+	                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr, have_dy ? pads->dy_pad : nullptr);   // :1202-1205
 	if (st) return st;
 	if (d_del_x) { st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st; }
 	if (cin != cout) {                                                                                                                  // :1208-1220

@@ -33,7 +33,7 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
-	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
+	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
 	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
@@ -72,6 +72,7 @@ struct bla_unet {
 	// backward
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
 	TimeJob* time_jobs = nullptr;                // device, one per ResNet block (batch > 1)
+	float* dy_pad[4] = {nullptr, nullptr, nullptr, nullptr};   // per resolution: padded gradient scratch of the blocks' first convolutions (halo zeroed once)
 	KernelPrepJob *prep_fwd = nullptr, *prep_bwd = nullptr;   // device: every convolution's kernel matrix re-ordered / flipped in ONE launch per pass
 	int n_prep_fwd = 0, n_prep_bwd = 0;
 	size_t prep_max = 0;
@@ -147,6 +148,15 @@ bla_status alloc_res(bla_unet* m, Res& r) {
 		if (r.cin > 4) { if ((st = dalloc(m, &r.pads.pad1, p1))) return st; BLA_HIP(hipMemsetAsync(r.pads.pad1, 0, p1 * sizeof(float), ctx().stream)); }
 		if ((st = dalloc(m, &r.pads.pad2, p2))) return st;
 		BLA_HIP(hipMemsetAsync(r.pads.pad2, 0, p2 * sizeof(float), ctx().stream));
+		// one scratch per resolution for the padded gradient in front of conv_1's data gradient (all blocks of a resolution share layout and halo)
+		int res_i = 0;
+		while (res_i < 3 && m->H[res_i] != r.h) res_i++;
+		const size_t widest = (size_t)m->batch * std::max(std::max(m->cfg.dims[0], m->cfg.dims[1]), std::max(m->cfg.dims[2], m->cfg.dims[3])) * L.plane;
+		if (!m->dy_pad[res_i]) {
+			if ((st = dalloc(m, &m->dy_pad[res_i], widest))) return st;
+			BLA_HIP(hipMemsetAsync(m->dy_pad[res_i], 0, widest * sizeof(float), ctx().stream));
+		}
+		r.pads.dy_pad = m->dy_pad[res_i];
 	}
 	return BLA_OK;
 }
