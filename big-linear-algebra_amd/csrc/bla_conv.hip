@@ -977,9 +977,11 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 			const int splits3 = gather3_splits(a.M, a.N * batch, a.K);
 			const size_t slab_bytes = splits3 > 1 ? ((size_t)splits3 * a.M * a.N * batch * sizeof(float) + 255) / 256 * 256 : 0;
 			void* ws;
-			st = ensure_workspace(slab_bytes + (a.padded_src ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
+			// (a 1x1 kernel on rows of whole float4 has no halo and no row padding: the image IS its padded copy)
+			const float* ready = a.padded_src ? a.padded_src : (a.g.k == 1 && a.g.s == 1 && a.g.w % 4 == 0 && (uintptr_t)a.img % 16 == 0 ? a.img : nullptr);
+			st = ensure_workspace(slab_bytes + (ready ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;
-			const float* padded = a.padded_src;
+			const float* padded = ready;
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
@@ -999,9 +1001,11 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 			// transposed product on the padded copy -- taps are the rows, both operands stream in 16-byte chunks
 			const size_t slab_bytes = ((size_t)gather_gemm_splits(4, batch, a.N, a.M, a.K) * a.M * a.N * sizeof(float) + 255) / 256 * 256;
 			void* ws;
-			st = ensure_workspace(slab_bytes + (a.padded_src ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
+			// (a 1x1 kernel on rows of whole float4 has no halo and no row padding: the image IS its padded copy)
+			const float* ready = a.padded_src ? a.padded_src : (a.g.k == 1 && a.g.s == 1 && a.g.w % 4 == 0 && (uintptr_t)a.img % 16 == 0 ? a.img : nullptr);
+			st = ensure_workspace(slab_bytes + (ready ? 0 : copy_floats * sizeof(float)) + 64, &ws);   // [slabs][padded copy]
 			if (st) return st;
-			const float* padded = a.padded_src;
+			const float* padded = ready;
 			const int2 *taps, *pix;
 			st = get_padded_tables(s, a.g, &taps, &pix);
 			if (st) return st;
