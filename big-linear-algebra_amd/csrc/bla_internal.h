@@ -102,7 +102,8 @@ enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
 // the forward pass's norm kernels fill them and say so (have1 / have2), both convolutions and both weight gradients then gather from them
 struct ResnetPads { float* pad1; float* pad2; bool have1, have2;
                     const float *k1_fwd, *k2_fwd, *k1_bwd, *k2_bwd;
-                    float* dy_pad; };   // scratch of the block's resolution (B*cout planes, halo zeroed once): the padded gradient the first convolution's data gradient reads   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
+                    float* dy_pad;
+                    float* g_res; };   // scratch of B*cin*hw floats: the 1x1 residual convolution's data gradient, added inside the last norm gradient instead of by a pass of its own   // scratch of the block's resolution (B*cout planes, halo zeroed once): the padded gradient the first convolution's data gradient reads   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
 bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
                                  float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
 bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,

@@ -528,8 +528,18 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	st = conv2d_backward_batched(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
 	                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr, have_dy ? pads->dy_pad : nullptr);   // :1202-1205
 	if (st) return st;
-	if (d_del_x) { st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : nullptr); if (st) return st; }
-	if (cin != cout) {                                                                                                                  // :1208-1220
+	// residual connection through the 1x1 convolution, :1208-1220.  With a scratch of the caller's (pads->g_res) its data gradient is formed FIRST and rides
+	// into del_x as the addend of the last norm gradient (the same d + addend per element as the separate add, :1219); without, one more pass adds it
+	const bool res_first = cin != cout && d_del_x && pads && pads->g_res;
+	if (res_first) {
+		// (sc->g_in still holds the first convolution's data gradient: the residual's goes to the scratch)
+		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, pads->g_res, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
+	}
+	if (d_del_x) {
+		st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : (res_first ? pads->g_res : nullptr));
+		if (st) return st;
+	}
+	if (cin != cout && !res_first) {
 		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
 		if (d_del_x) return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)batch * cin * hw);
 	}

@@ -33,7 +33,7 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
-	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
+	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
 	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
@@ -72,6 +72,7 @@ struct bla_unet {
 	// backward
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
 	TimeJob* time_jobs = nullptr;                // device, one per ResNet block (batch > 1)
+	float* g_res = nullptr;                                      // batched: the residual 1x1 convolutions' data gradient (largest block input)
 	float* dy_pad[4] = {nullptr, nullptr, nullptr, nullptr};   // per resolution: padded gradient scratch of the blocks' first convolutions (halo zeroed once)
 	KernelPrepJob *prep_fwd = nullptr, *prep_bwd = nullptr;   // device: every convolution's kernel matrix re-ordered / flipped in ONE launch per pass
 	int n_prep_fwd = 0, n_prep_bwd = 0;
@@ -140,6 +141,12 @@ bla_status alloc_res(bla_unet* m, Res& r) {
 	if (r.cin != r.cout && (st = dalloc(m, &r.ws.res, r.cout * hw))) return st;
 	if (m->batch == 1) return BLA_OK;
 	if ((st = dalloc(m, &r.dtb, (size_t)r.cout * m->batch))) return st;
+	if (r.cin != r.cout && r.cin > 4) {      // (one scratch for all blocks: they run one after the other)
+		size_t widest = 0;
+		for (int i = 0; i < 18; i++) if (m->res[i].cin != m->res[i].cout) widest = std::max(widest, (size_t)m->batch * m->res[i].cin * m->res[i].h * m->res[i].w);
+		if (!m->g_res && (st = dalloc(m, &m->g_res, widest))) return st;
+		r.pads.g_res = m->g_res;
+	}
 	// padded copies (conv_padded_layout): only where a tiled convolution will read them -- not for the 3-channel input of the first block (direct kernels)
 	static const bool pads_on = [] { const char* e = getenv("BLA_UNET_PADS"); return !(e && e[0] == '0'); }();
 	const PadLayout L = conv_padded_layout(r.h, r.w, m->cfg.kernel, 1);
