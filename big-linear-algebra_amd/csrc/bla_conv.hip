@@ -1524,6 +1524,54 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 			BLA_HIP(hipGetLastError());
 			return launch_backward_pair(s, aw, ad, batch);
 		}
+		// both on the tiled gather kernels (a batch that fills the chip): ONE launch for the two products -- the data gradient's workgroups move in as the weight
+		// gradient's finish, each product's prologue / drain / tail under the other's body (gather_pair_kernel).  BLA_CONV_PAIR=0: one launch each.
+		static const bool pair_on = [] { const char* e = getenv("BLA_CONV_PAIR"); return !(e && e[0] == '0'); }();
+		const PaddedGeom pgw = padded_geom(aw.g), pgd = padded_geom(ad.g);
+		const size_t copy_w = (size_t)batch * aw.g.c * pgw.plane_floats, copy_d = (size_t)batch * ad.g.c * pgd.plane_floats;
+		const bool fits_w = copy_w < ((size_t)1 << 29) && (long)batch * aw.M * aw.g.ho * aw.g.wo < (1L << 29);
+		ad.padded_src = k % 2 == 1 ? dy_padded : nullptr;
+		const FwdPath dpath = plan_forward(ad, batch).path;
+		static const long pair_max_cols = [] { const char* e = getenv("BLA_CONV_PAIR_COLS"); return e && *e ? atol(e) : 2048L; }();
+		if (pair_on && (long)ad.N * batch <= pair_max_cols && use_tiled_gather(aw, batch, 2) && fits_w && aw.g.wo % 4 == 0 && aw.N % 4 == 0 && gather_pair_fits(4, aw.N, aw.M) &&
+		    (dpath == FWD_TILED_WINDOW || (dpath == FWD_TILED_PADDED && gather_pair_fits(3, ad.M, ad.N * batch)))) {
+			const int2 *taps_w, *pix_w, *taps_d = nullptr, *pix_d = nullptr;
+			st = get_padded_tables(s, aw.g, &taps_w, &pix_w);
+			if (st) return st;
+			if (dpath == FWD_TILED_PADDED) { st = get_padded_tables(s, ad.g, &taps_d, &pix_d); if (st) return st; }
+			// the two products as gather_gemm would take them (launch_implicit's weight-gradient and forward branches)
+			GatherProduct gw = {4, aw.N, aw.M, aw.K * batch, aw.A, aw.lda, aw.out, aw.ldo, nullptr, pix_w, taps_w, pgw.hh, pgw.wh, aw.K, (int)(aw.g.c * pgw.plane_floats), GatherEpilogue{}};
+			GatherProduct gd = dpath == FWD_TILED_WINDOW
+				? GatherProduct{7, ad.M, ad.N * batch, ad.K, nullptr, ad.K, ad.out, ad.ldo, ad.img, nullptr, nullptr, ad.g.h, ad.g.w, ad.N, (int)y_sz, GatherEpilogue{}}
+				: GatherProduct{3, ad.M, ad.N * batch, ad.K, nullptr, ad.lda, ad.out, ad.ldo, nullptr, taps_d, pix_d, pgd.hh, pgd.wh, ad.N, (int)(ad.g.c * pgd.plane_floats), GatherEpilogue{}};
+			// one workspace: [weight-gradient slabs][data-gradient slabs][padded x][padded del_y][kernel matrix in the data gradient's form], each only where needed
+			const float* xp = x_padded ? x_padded : (aw.g.k == 1 && aw.g.w % 4 == 0 && (uintptr_t)d_x % 16 == 0 ? d_x : nullptr);
+			const float* yp = dpath == FWD_TILED_PADDED ? (ad.padded_src ? ad.padded_src : (ad.g.k == 1 && ad.g.w % 4 == 0 && (uintptr_t)d_del_y % 16 == 0 ? d_del_y : nullptr)) : d_del_y;
+			const bool need_kern = !prepared;
+			auto up = [](size_t floats) { return (floats + 63) / 64 * 64; };
+			const size_t slab_w = up(gather_product_slab_floats(gw, batch)), slab_d = up(gather_product_slab_floats(gd, batch));
+			const size_t pad_w = xp ? 0 : up(copy_w), pad_d = yp ? 0 : up(copy_d), kern_f = need_kern && dpath == FWD_TILED_WINDOW ? up((size_t)ad.M * ad.K) : 0;
+			void* ws;
+			st = ensure_workspace((slab_w + slab_d + pad_w + pad_d + kern_f) * sizeof(float) + 64, &ws);
+			if (st) return st;
+			float* base = (float*)ws;
+			float *w_slab = base, *d_slab = base + slab_w, *w_pad = d_slab + slab_d, *d_pad = w_pad + pad_w, *kbuf = d_pad + pad_d;
+			if (!xp) { launch_pad_split(s, d_x, w_pad, (unsigned)(batch * aw.g.c), aw.g.h, aw.g.w, aw.g.pt, aw.g.pl, 1, (unsigned)pgw.hh, (unsigned)pgw.wh); xp = w_pad; }
+			if (!yp) { launch_pad_split(s, d_del_y, d_pad, (unsigned)(batch * ad.g.c), ad.g.h, ad.g.w, ad.g.pt, ad.g.pl, 1, (unsigned)pgd.hh, (unsigned)pgd.wh); yp = d_pad; }
+			if (prepared) gd.A = prepared;      // (conv_kernel_prep_mode 2 / 3: flipped, and window-ordered where the window kernel runs)
+			else if (dpath == FWD_TILED_WINDOW) {
+				hipLaunchKernelGGL(window_order_flipped_kernel, dim3(grid_for((size_t)ad.M * ad.K)), dim3(kThreads), 0, s, d_kern, kbuf, ad.M, ad.g.c);
+				gd.A = kbuf;
+			} else {
+				hipLaunchKernelGGL(flip_kernels_kernel, dim3(grid_for((size_t)f_n * c_in * k * k)), dim3(kThreads), 0, s, d_kern, d_scratch, f_n, c_in, k);
+				gd.A = d_scratch;
+			}
+			BLA_HIP(hipGetLastError());
+			gw.img = xp;
+			if (dpath == FWD_TILED_PADDED) gd.img = yp;
+			return gather_pair_products(s, batch, gw, w_slab, gd, d_slab);
+		}
+		ad.padded_src = nullptr;
 	}
 	if (d_del_kern) {
 		BLA_REQUIRE(d_x, BLA_ERR_INVALID, "weight gradient needs the forward input");

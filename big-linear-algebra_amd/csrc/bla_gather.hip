@@ -170,4 +170,99 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	return BLA_OK;
 }
 
+// ---- both gradients of one convolution in one launch (gather_pair_kernel) -----------------------------------------------------------------------------
+namespace { struct GatherPlan { GemmArgs a; dim3 grid; size_t lds; int mode, gw, hwo; size_t slab_floats; GatherEpilogue ep; }; }
+static bla_status gather_plan(int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img, const int2* ktab, const int2* ntab, int H, int W,
+                              int HWo, int img_stride, const GatherEpilogue* ep, GatherPlan* out);
+// gather_plan = the planning half of gather_gemm for the forms the pair takes: the weight gradient on the half-slab mode 4, the data gradient on mode 7
+// or on the half-slab mode 3 (whole 128 x 128 tiles).  Everything but the slab address: the caller lays both products' slabs out in one workspace.
+bool gather_pair_fits(int mode, int M, int N) { return mode == 7 || gather_hs(mode, M, N); }
+static bla_status gather_plan(int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img, const int2* ktab, const int2* ntab, int H, int W,
+                              int HWo, int img_stride, const GatherEpilogue* ep, GatherPlan* out) {
+	BLA_REQUIRE(out && (mode == 3 || mode == 4 || mode == 7) && gather_pair_fits(mode, M, N), BLA_ERR_INVALID, "gather_plan: mode %d M=%d N=%d", mode, M, N);
+	GemmArgs a = {};
+	a.alpha = 1.f; a.beta = 0.f; a.act = BLA_ACT_NONE;
+	a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+	a.g_img = img; a.g_zero = zero_word(); a.g_mode = mode; a.g_H = H; a.g_W = W; a.g_HWo = HWo; a.g_img_stride = img_stride;
+	a.tiles_m = M / 128; a.tiles_n = N / 128;
+	out->mode = mode; out->gw = 0;
+	if (mode == 7) {
+		const int ch = HWo > 0 ? img_stride / HWo : 0;
+		BLA_REQUIRE(M % 128 == 0 && N % 128 == 0 && HWo == H * W && HWo % 128 == 0 && (W == 16 || W == 32) && ch % 16 == 0 && ch > 0 && K == 9 * ch && lda == K &&
+		            (uintptr_t)A % 16 == 0 && (long)batch * img_stride < (1L << 29) && (long)N * M < (1L << 31), BLA_ERR_INVALID, "mode 7 shape (M=%d N=%d K=%d H=%d W=%d C=%d)", M, N, K, H, W, ch);
+		a.A = A; a.lda = lda; a.k_per_split = K; a.splits = 1;
+		if (ep) { a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2; }
+		const size_t plane = (size_t)(128 / W + 2) * W;
+		out->lds = (2 * 128 * 16 + 2 * 16 * plane + 8) * sizeof(float);
+		out->grid = dim3((unsigned)(a.tiles_m * a.tiles_n), 1, 1);
+		out->gw = W;
+	} else {
+		BLA_REQUIRE(mode != 3 || (N % 4 == 0 && HWo % 4 == 0), BLA_ERR_INVALID, "mode 3 needs pixel counts that are multiples of 4");
+		BLA_REQUIRE(K > 0 && K % 16 == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && (mode != 4 || HWo % 16 == 0) && (long)batch * img_stride < (1L << 29), BLA_ERR_INVALID,
+		            "gathered product needs K %% 16 == 0 and a 16-byte aligned dense operand (M=%d N=%d K=%d lda=%d)", M, N, K, lda);
+		if (mode == 4) { a.A = nullptr; a.lda = 0; a.B = A; a.ldb = lda; } else { a.A = A; a.lda = lda; }
+		a.g_ktab = ktab; a.g_ntab = ntab;
+		const int splits = mode == 3 ? gather3_splits(M, N, K) : gather_gemm_splits(mode, batch, M, N, HWo);
+		a.k_per_split = mode == 4 ? gather_k_per_split(mode, batch, M, N, HWo) : (K / 16 + splits - 1) / splits * 16;
+		a.splits = splits;
+		if (ep && (ep->bias || ep->out2) && splits == 1) { a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2; }
+		out->lds = 2 * (128 + 128) * 16 * sizeof(float);
+		out->grid = dim3((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
+	}
+	out->a = a;
+	out->slab_floats = a.splits > 1 ? (size_t)a.splits * M * N : 0;
+	out->ep = ep ? *ep : GatherEpilogue{};
+	out->hwo = HWo;
+	return BLA_OK;
+}
+// w: a mode-4 plan, d: a mode-3 or mode-7 plan; slabs (a.slab) set by the caller where slab_floats > 0.  One launch, then the folds.
+static bla_status gather_pair(hipStream_t s, const GatherPlan& w, const GatherPlan& d) {
+	BLA_REQUIRE(w.mode == 4 && (d.mode == 3 || d.mode == 7) && (w.slab_floats == 0 || w.a.slab) && (d.slab_floats == 0 || d.a.slab), BLA_ERR_INVALID, "gather_pair: bad plans");
+	const int wx = (int)w.grid.x, wz = (int)w.grid.z, dx = (int)d.grid.x, dz = (int)d.grid.z, blocks_w = wx * wz;
+	const dim3 grid((unsigned)(blocks_w + dx * dz)), block(256);
+	const size_t lds = w.lds > d.lds ? w.lds : d.lds;
+	if (d.mode == 7 && d.gw == 32) hipLaunchKernelGGL((gather_pair_kernel<7, 32>), grid, block, lds, s, w.a, d.a, blocks_w, wx, wz, dx, dz);
+	else if (d.mode == 7) hipLaunchKernelGGL((gather_pair_kernel<7, 16>), grid, block, lds, s, w.a, d.a, blocks_w, wx, wz, dx, dz);
+	else hipLaunchKernelGGL((gather_pair_kernel<3, 0>), grid, block, lds, s, w.a, d.a, blocks_w, wx, wz, dx, dz);
+	BLA_HIP(hipGetLastError());
+	if (w.a.splits > 1) {
+		GemmArgs r = w.a;
+		r.M = w.a.N; r.N = w.a.M;      // the slabs hold the transposed tile: [split][N][M] -> C [N][M]
+		BLA_HIP(launch_splitk_reduce(r, s));
+	}
+	if (d.a.splits > 1) {
+		const bool with_ep = d.ep.bias || d.ep.out2;
+		if (with_ep) {
+			const size_t total4 = (size_t)d.a.M * d.a.N / 4, blocks = (total4 + 255) / 256;
+			hipLaunchKernelGGL(gather_fold_epilogue_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, (const float4*)d.a.slab, (float4*)d.a.C, d.a.splits, total4,
+			                   d.ep.bias, d.ep.bias_stride, (const float4*)d.ep.add, (float4*)d.ep.out2, d.a.M, d.hwo / 4);
+			BLA_HIP(hipGetLastError());
+		} else {
+			GemmArgs r = d.a;
+			r.ldc = r.N;
+			BLA_HIP(launch_splitk_reduce(r, s));
+		}
+	}
+	return BLA_OK;
+}
+
+static bla_status plan_of(const GatherProduct& g, int batch, GatherPlan* out) {
+	return gather_plan(g.mode, batch, g.M, g.N, g.K, g.A, g.lda, g.C, g.ldc, g.img, g.ktab, g.ntab, g.H, g.W, g.HWo, g.img_stride, &g.ep, out);
+}
+size_t gather_product_slab_floats(const GatherProduct& g, int batch) {
+	if (g.mode == 7) return 0;
+	const int splits = g.mode == 3 ? gather3_splits(g.M, g.N, g.K) : gather_gemm_splits(g.mode, batch, g.M, g.N, g.HWo);
+	return splits > 1 ? (size_t)splits * g.M * g.N : 0;
+}
+bla_status gather_pair_products(hipStream_t s, int batch, const GatherProduct& w, float* w_slab, const GatherProduct& d, float* d_slab) {
+	GatherPlan pw, pd;
+	bla_status st = plan_of(w, batch, &pw);
+	if (st) return st;
+	st = plan_of(d, batch, &pd);
+	if (st) return st;
+	pw.a.slab = pw.slab_floats ? w_slab : nullptr;
+	pd.a.slab = pd.slab_floats ? d_slab : nullptr;
+	return gather_pair(s, pw, pd);
+}
+
 }  // namespace bla

@@ -117,7 +117,9 @@ struct KcImage {  // ROWS x BK floats, K contiguous
 // block (64x64: a lone wave's waits and barrier skew leave the matrix pipe idle).
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false,
           int WK = 1, int GW = 0>
-__global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, const int blk_y, const int blk_z, const int grid_x, const int grid_z) {
+	// (blk_* / grid_*: this workgroup's place in ITS product's grid -- blockIdx / gridDim for a launch of one product, a slice of the linear grid when two
+	// products share a launch, gather_pair_kernel below)
 	static_assert(GATHER != 7 || (HS && (GW == 16 || GW == 32) && WM == 2 && WN == 2 && BN == 128), "mode 7: half-slab pipeline, image rows of 16 or 32 pixels");
 	static_assert(GATHER == 0 || (AKC && BKC == (GATHER == 4) && NBUF == 2 && !PERSIST && BM == 128 && (BN == 128 || (BN == 256 && GATHER == 3 && HS)) && BK == 16 && WM * WN == 4),
 	              "gather variants: A K-contiguous; modes 1-3 gather B as a [16][128] image (mode 3 on the half-slab pipeline: [16][256] too), mode 4 gathers A and takes a K-contiguous B");
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	const int wm0 = (wsp / WN) * (BM / WM), wn0 = (wsp % WN) * (BN / WN);
 
 	if (GATHER == 3 && HS && p.g_ncls > 1) {
-		const GatherClass c = p.g_cls[blockIdx.y];
+		const GatherClass c = p.g_cls[blk_y];
 		p.A = c.A; p.C = c.C; p.g_ktab = c.ktab; p.K = c.K; p.lda = c.K;
 	}
 	// virtual block id -> tile origin: XCD remap, then groups of 8 tile-rows walked column by column
@@ -160,10 +162,10 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 	// deals consecutive workgroup ids round-robin to the 8 XCDs -- with (tile, split) = (blockIdx.x, blockIdx.z) the tiles of a split land on
 	// different XCDs and each L2 fetches that split's del_y for itself (349 MB of fills for 68 MB of operands at 128->128 @32x32 x64).  So XCD x takes
 	// the splits s = x (mod 8) and walks them tile by tile: the tiles of a split are neighbours in ONE XCD's dispatch order and share its L2.
-	int vblock = blockIdx.x, zsplit = blockIdx.z;
-	if (GATHER == 4 && (gridDim.z & 7) == 0) {
-		const int lin = blockIdx.z * gridDim.x + blockIdx.x, i = lin >> 3;
-		zsplit = (i / (int)gridDim.x) * 8 + (lin & 7); vblock = i % (int)gridDim.x;
+	int vblock = blk_x, zsplit = blk_z;
+	if (GATHER == 4 && (grid_z & 7) == 0) {
+		const int lin = blk_z * grid_x + blk_x, i = lin >> 3;
+		zsplit = (i / grid_x) * 8 + (lin & 7); vblock = i % grid_x;
 	}
 	tile_origin(vblock, m0, n0);
 	const int k_begin = zsplit * p.k_per_split;
@@ -998,7 +1000,7 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		};
 		auto plan_next = [&](int vb_next) {   // slab-0 pointers of the tile after the one being computed (past the end: this tile
 			int tm0, tn0;                      // again -- a harmless re-fetch into a buffer nobody reads)
-			tile_origin(vb_next < total ? vb_next : (int)blockIdx.x, tm0, tn0);
+			tile_origin(vb_next < total ? vb_next : blk_x, tm0, tn0);
 			const float* sa[A_NI]; const float* sb[B_NI];
 #pragma unroll
 			for (int i = 0; i < A_NI; i++) sa[i] = ga[i];
@@ -1026,16 +1028,16 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 			rest(pa, pb);
 			__builtin_amdgcn_sched_barrier(0);
 		};
-		if (nkt > 0 && (int)blockIdx.x < total) {
+		if (nkt > 0 && blk_x < total) {
 			dma_next(0);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 #pragma unroll
 			for (int kk = 0; kk < KK; kk++) frags(lds, lds + A_SZ, kk, fa0[kk], fb0[kk]);
 			dma_next(1);
-			for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+			for (int vb = blk_x; vb < total; vb += grid_x) {
 				tile_origin(vb, m0, n0);
-				plan_next(vb + gridDim.x);
+				plan_next(vb + grid_x);
 				__builtin_amdgcn_sched_barrier(0);
 				for (int kt = 0; kt < nkt; kt += 2) {
 					pstep(0, fa0, fb0, fa1, fb1);
@@ -1161,6 +1163,24 @@ __global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(
 		}
 	}
 	if constexpr (!PERSIST) store_tile();
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int MINW = 1, int NBUF = 2, bool PERSIST = false, int GATHER = 0, bool RCG = false, bool HS = false,
+          int WK = 1, int GW = 0>
+__global__ void __launch_bounds__(WM * WN * WK * 64, MINW) gemm_f32_glds_kernel(GemmArgs p) {
+	gemm_f32_glds_body<BM, BN, BK, WM, WN, AKC, BKC, MINW, NBUF, PERSIST, GATHER, RCG, HS, WK, GW>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.z);
+}
+
+// Both gradients of one batched convolution in ONE launch: workgroups [0, blocks_w) run the weight gradient (gather mode 4; (tile, split) = (i % wx, i / wx)),
+// the rest the data gradient (DG = gather mode 7 with rows of GW pixels, or mode 3; (tile, split) = (j % dx, j / dx)).  Neither reads what the other
+// writes; dealt out in this order the data gradient's workgroups move in as the weight gradient's finish, so one product's prologue, drain and tail are
+// covered by the other's body instead of standing alone on an idle chip (two contexts running them side by side measured 375 -> 331 us at 128 -> 128
+// @32x32 x64; forking to a second stream per convolution cost as much in cross-stream waits as it gained).  Registers / LDS: the larger of the two.
+template <int DG, int GW>
+__global__ void __launch_bounds__(256, 1) gather_pair_kernel(GemmArgs w, GemmArgs d, int blocks_w, int wx, int wz, int dx, int dz) {
+	const int b = (int)blockIdx.x;
+	if (b < blocks_w) gemm_f32_glds_body<128, 128, 16, 2, 2, true, true, 1, 2, false, 4, false, true, 1, 0>(w, b % wx, 0, b / wx, wx, wz);
+	else gemm_f32_glds_body<128, 128, 16, 2, 2, true, false, 1, 2, false, DG, false, true, 1, GW>(d, (b - blocks_w) % dx, 0, (b - blocks_w) / dx, dx, dz);
 }
 
 // (bla_gemm.hip) fold of split-K slabs: fixed order, epilogue applied

@@ -54,6 +54,13 @@ bool gather_classes_fit(int ncls, int M, int N);
 bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const GatherClass* cls, const GatherClass* d_cls, int ncls, int ldc, const float* img,
                                const int2* ntab, int H, int W, int HWo, int img_stride);
 
+// Both gradients of one batched convolution in ONE launch (gather_pair_kernel, bla_gemm_kernel.h): w = the weight gradient as gather_gemm(mode 4, ...) takes it,
+// d = the data gradient as gather_gemm(mode 7 or 3, ...) takes it (whole 128 x 128 tiles: gather_pair_fits); slabs: gather_product_slab_floats floats each (0: none)
+struct GatherProduct { int mode, M, N, K; const float* A; int lda; float* C; int ldc; const float* img; const int2* ktab; const int2* ntab; int H, W, HWo, img_stride; GatherEpilogue ep; };
+bool gather_pair_fits(int mode, int M, int N);
+size_t gather_product_slab_floats(const GatherProduct& g, int batch);
+bla_status gather_pair_products(hipStream_t s, int batch, const GatherProduct& w, float* w_slab, const GatherProduct& d, float* d_slab);
+
 // bla_conv.hip: implicit-GEMM convolution with the adds the U-Net puts behind it: out = conv + ep_bias[image * ep_bias_stride + channel];
 // ep_out2 = out + ep_add, both optional.  One image: folded into the store; a batch: one pass behind the product.
 // x_padded (batched callers): the zero-padded copy of d_x in conv_padded_layout(h, w, k, stride), written by the producer of d_x (the norm kernel in front):
