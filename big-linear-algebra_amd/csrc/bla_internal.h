@@ -18,6 +18,14 @@ struct Context {
 	size_t workspace_bytes = 0;
 	void* workspace2 = nullptr;     // a second grow-only scratch for operands that must survive a kernel which uses the first (dilated gradients)
 	size_t workspace2_bytes = 0;
+	// The side lane: a second stream with its own scratch and a fork / join event pair.  The batched U-Net issues its weight gradients there (side_lane_fork:
+	// the lane waits for what the caller's stream has issued so far; nothing on the caller's stream waits for the lane until side_lane_join) so that they run
+	// beside the data gradients, norms and glue of the main chain.  While side_lane is set, ensure_workspace hands out the lane's scratch.
+	hipStream_t side_stream = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	void* workspace3 = nullptr;
+	size_t workspace3_bytes = 0;
+	bool side_lane = false;
 	unsigned* tile_counters = nullptr;   // 16384 arrival counters for in-launch split-K, zero between launches
 	int num_cus = 0;
 	char arch[64] = {0};
@@ -31,6 +39,11 @@ bla_status require_ready();
 // Scratch of at least `bytes` (device); valid until the next ensure_workspace call that grows it.
 bla_status ensure_workspace(size_t bytes, void** out);
 bla_status ensure_workspace2(size_t bytes, void** out);
+// side lane (see Context): fork = the lane's stream (returned) waits for everything issued on `main` so far and becomes the target of ensure_workspace until
+// side_lane_done(); join = `main` waits for everything issued on the lane
+bla_status side_lane_fork(hipStream_t main, hipStream_t* lane);
+void side_lane_done();
+bla_status side_lane_join(hipStream_t main);
 // out[i] = sum_{j<len} m[i*stride + j], i < count (bla_elementwise.hip)
 bla_status window_sum(void* stream, const float* m, int count, int len, int stride, float* out);
 inline hipStream_t pick_stream(void* s) { return s ? (hipStream_t)s : ctx().stream; }
@@ -104,13 +117,15 @@ bla_status group_norm_ddx_gated(void* stream, const float* d_source, float* d_de
 
 // bla_unet.hip: the batched ResNet block with the time-embedding projection hoisted out (bla_unet_model.hip forms all blocks' projections / time gradients in
 // one launch each): RESNET_TDENSE_READY = ws->tdense is already filled; RESNET_DEFER_TIME_GRADS = only the per-image channel sums go to d_dtb
-enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2 };
+enum { RESNET_TDENSE_READY = 1, RESNET_DEFER_TIME_GRADS = 2, RESNET_WGRAD_SIDE = 4 };   // WGRAD_SIDE: the block's weight gradients go to the context's side lane
+                                                                                         // (the caller keeps del_out and pads->g_out_b intact until it has joined the lane)
 // padded copies of a block's two convolution inputs (relu1: B*cin planes, dp: B*cout planes; conv_padded_layout(h, w, k, 1); halo zeroed once by the owner):
 // the forward pass's norm kernels fill them and say so (have1 / have2), both convolutions and both weight gradients then gather from them
 struct ResnetPads { float* pad1; float* pad2; bool have1, have2;
                     const float *k1_fwd, *k2_fwd, *k1_bwd, *k2_bwd;
                     float* dy_pad;
-                    float* g_res; };   // scratch of B*cin*hw floats: the 1x1 residual convolution's data gradient, added inside the last norm gradient instead of by a pass of its own   // scratch of the block's resolution (B*cout planes, halo zeroed once): the padded gradient the first convolution's data gradient reads   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
+                    float* g_res;
+                    float* g_out_b; };   // RESNET_WGRAD_SIDE: this block's own buffer for the gradient in front of the first convolution (the side lane reads it later)   // scratch of B*cin*hw floats: the 1x1 residual convolution's data gradient, added inside the last norm gradient instead of by a pass of its own   // scratch of the block's resolution (B*cout planes, halo zeroed once): the padded gradient the first convolution's data gradient reads   // the two convolutions' prepared kernel matrices (KernelPrepJob outputs) or NULL
 bla_status resnet_forward_single(void* stream, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop, const bla_resnet_ws* ws,
                                  float* d_result, int h, int w, int cin, int cout, int k, int tdim, int group_size, int flags);
 bla_status resnet_forward_batched(void* stream, int batch, const float* d_x, const float* d_temb, const bla_resnet_params* p, const unsigned char* d_drop,

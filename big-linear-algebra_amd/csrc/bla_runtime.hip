@@ -49,8 +49,40 @@ void rand_guard_leave() {
 	if (--g_rand_depth == 0 && g_rand_saved) { (void)setstate(g_rand_saved); g_rand_saved = nullptr; }
 }
 
+bla_status side_lane_fork(hipStream_t main, hipStream_t* lane) {
+	Context& c = ctx();
+	if (!c.side_stream) {
+		BLA_HIP(hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking));
+		BLA_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+		BLA_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+	}
+	BLA_HIP(hipEventRecord(c.ev_fork, main));
+	BLA_HIP(hipStreamWaitEvent(c.side_stream, c.ev_fork, 0));
+	c.side_lane = true;
+	*lane = c.side_stream;
+	return BLA_OK;
+}
+void side_lane_done() { ctx().side_lane = false; }
+bla_status side_lane_join(hipStream_t main) {
+	Context& c = ctx();
+	if (!c.side_stream) return BLA_OK;
+	BLA_HIP(hipEventRecord(c.ev_join, c.side_stream));
+	BLA_HIP(hipStreamWaitEvent(main, c.ev_join, 0));
+	return BLA_OK;
+}
+
 bla_status ensure_workspace(size_t bytes, void** out) {
 	Context& c = ctx();
+	if (c.side_lane) {     // issued for the side lane: its own scratch
+		if (bytes > c.workspace3_bytes) {
+			if (c.workspace3) { BLA_HIP(hipDeviceSynchronize()); BLA_HIP(hipFree(c.workspace3)); c.workspace3 = nullptr; c.workspace3_bytes = 0; }
+			const size_t want = bytes < (size_t)(64u << 20) ? (size_t)(64u << 20) : bytes;
+			BLA_HIP(hipMalloc(&c.workspace3, want));
+			c.workspace3_bytes = want;
+		}
+		*out = c.workspace3;
+		return BLA_OK;
+	}
 	if (bytes > c.workspace_bytes) {
 		// Grow-only.  Callers serialise on one stream, so freeing after a sync is safe.
 		if (c.workspace) {
@@ -137,9 +169,13 @@ int bla_device_count(void) {
 
 // release whatever a context holds, ready or not (a context whose set-up failed half way holds a stream but is not ready)
 static void close_context(Context& c) {
-	if (!c.stream && !c.workspace && !c.workspace2 && !c.tile_counters) { c = Context(); return; }
+	if (!c.stream && !c.workspace && !c.workspace2 && !c.tile_counters && !c.side_stream && !c.workspace3) { c = Context(); return; }
 	RandStreamGuard keep_callers_rand_stream;
 	if (c.device >= 0) { (void)hipSetDevice(c.device); (void)hipDeviceSynchronize(); }
+	if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
+	if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+	if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+	if (c.workspace3) (void)hipFree(c.workspace3);
 	if (c.stream) (void)hipStreamDestroy(c.stream);
 	if (c.workspace) (void)hipFree(c.workspace);
 	if (c.workspace2) (void)hipFree(c.workspace2);

@@ -508,39 +508,58 @@ bla_status bla::resnet_backward_batched(void* stream, int batch, const float* d_
 	            sc->g_out_b && sc->g_in && sc->flip, BLA_ERR_INVALID, "null operand");
 	BLA_REQUIRE(cin == cout || (p->res && g->res), BLA_ERR_INVALID, "Cin != Cout needs the residual 1x1 kernels and their gradient");
 	const int hw = h * w;
-	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1, pads && pads->have2 ? pads->pad2 : nullptr,
-	                             pads ? pads->k2_bwd : nullptr);
+	// RESNET_WGRAD_SIDE: the three weight gradients go to the context's side lane (each after a fork: the lane waits for what this stream has issued so far),
+	// the data gradients, norms and sums stay here -- MFMA-bound products beside HBM-bound passes instead of one after the other.  The caller joins the lane
+	// once, at the end of its pass, and keeps what the lane reads (del_out, g_out_b, the activations and their padded copies) intact until then.
+	const bool side = (flags & RESNET_WGRAD_SIDE) && pads && pads->g_out_b;
+	float* const g_out_b = side ? pads->g_out_b : sc->g_out_b;
+	hipStream_t main_s = pick_stream(stream);
+	auto wgrad_on_lane = [&](const float* del_y, const float* x, const float* kern, float* gkern, int kk, int ci, int co, const float* x_padded) -> bla_status {
+		hipStream_t lane;
+		bla_status s2 = side_lane_fork(main_s, &lane);
+		if (s2) return s2;
+		s2 = conv2d_backward_batched(lane, del_y, x, kern, gkern, nullptr, sc->flip, batch, h, w, kk, ci, co, 1, x_padded, nullptr, nullptr);
+		side_lane_done();
+		return s2;
+	};
+	if (side) { st = wgrad_on_lane(d_del_out, ws->dp, p->conv2, g->conv2, k, cout, cout, pads->have2 ? pads->pad2 : nullptr); if (st) return st; }
+	st = conv2d_backward_batched(stream, d_del_out, ws->dp, p->conv2, side ? nullptr : g->conv2, sc->g_out_a, sc->flip, batch, h, w, k, cout, cout, 1,
+	                             pads && pads->have2 ? pads->pad2 : nullptr, pads ? pads->k2_bwd : nullptr);
 	if (st) return st;                                                                                                                      // :1186-1189
 	// the gradient that reaches the first convolution also lands in the padded copy its data gradient gathers from -- where that product runs on the padded-copy
 	// kernel (prep mode 3) and someone wants it
 	const PadLayout L = pads && pads->dy_pad && d_del_x && k % 2 == 1 && conv_kernel_prep_mode(batch, h, w, k, cin, cout, 1, true) == 3 ? conv_padded_layout(h, w, k, 1) : PadLayout{};
 	const PadOut pod = {L.plane ? pads->dy_pad : nullptr, L};
 	bool have_dy = false;
-	st = gn_ddx_b(stream, batch, sc->g_out_a, sc->g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr, &pod, &have_dy); if (st) return st;
+	st = gn_ddx_b(stream, batch, sc->g_out_a, g_out_b, ws->c1, ws->mu2, ws->sd2, cout, group_size, hw, ws->dp, nullptr, &pod, &have_dy); if (st) return st;
 	// time-embedding projection, :1191-1199: per image the per-channel sums, then bias gradient = their sum over the images, weight gradient = temb^T . dtb
-	st = bla_col_sum_f32(stream, sc->g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
+	st = bla_col_sum_f32(stream, g_out_b, batch * cout, hw, d_dtb, BLA_COLSUM_INTENDED); if (st) return st;
 	if (!(flags & RESNET_DEFER_TIME_GRADS)) {
 		st = batch_sum(stream, d_dtb, g->time_b, batch, (size_t)cout); if (st) return st;
 		st = bla_gemm_f32(stream, 1, 0, tdim, cout, batch, d_temb, tdim, d_dtb, cout, g->time_w, cout, nullptr); if (st) return st;
 	}
 	// d_del_x == NULL: the gradient with respect to the block's input is not wanted (the first block of a network: nothing consumes it) -- the two data
 	// gradients and the last norm gradient are not formed, the weight gradients are
-	st = conv2d_backward_batched(stream, sc->g_out_b, ws->relu1, p->conv1, g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
-	                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr, have_dy ? pads->dy_pad : nullptr);   // :1202-1205
-	if (st) return st;
+	if (side) { st = wgrad_on_lane(g_out_b, ws->relu1, p->conv1, g->conv1, k, cin, cout, pads->have1 ? pads->pad1 : nullptr); if (st) return st; }
+	if (!side || d_del_x) {
+		st = conv2d_backward_batched(stream, g_out_b, ws->relu1, p->conv1, side ? nullptr : g->conv1, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, k, cin, cout, 1,
+		                             pads && pads->have1 ? pads->pad1 : nullptr, pads && d_del_x ? pads->k1_bwd : nullptr, have_dy ? pads->dy_pad : nullptr);   // :1202-1205
+		if (st) return st;
+	}
 	// residual connection through the 1x1 convolution, :1208-1220.  With a scratch of the caller's (pads->g_res) its data gradient is formed FIRST and rides
 	// into del_x as the addend of the last norm gradient (the same d + addend per element as the separate add, :1219); without, one more pass adds it
 	const bool res_first = cin != cout && d_del_x && pads && pads->g_res;
+	if (side && cin != cout) { st = wgrad_on_lane(d_del_out, d_x, p->res, g->res, 1, cin, cout, nullptr); if (st) return st; }
 	if (res_first) {
 		// (sc->g_in still holds the first convolution's data gradient: the residual's goes to the scratch)
-		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, pads->g_res, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
+		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, side ? nullptr : g->res, pads->g_res, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
 	}
 	if (d_del_x) {
 		st = gn_ddx_b(stream, batch, sc->g_in, d_del_x, d_x, ws->mu1, ws->sd1, cin, group_size, hw, ws->relu1, cin == cout ? d_del_out : (res_first ? pads->g_res : nullptr));
 		if (st) return st;
 	}
-	if (cin != cout && !res_first) {
-		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, g->res, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
+	if (cin != cout && !res_first && !(side && !d_del_x)) {
+		st = bla_conv2d_backward_batched_f32(stream, d_del_out, d_x, p->res, side ? nullptr : g->res, d_del_x ? sc->g_in : nullptr, sc->flip, batch, h, w, 1, cin, cout, 1); if (st) return st;
 		if (d_del_x) return bla_add_f32(stream, d_del_x, sc->g_in, (size_t)batch * cin * hw);
 	}
 	return BLA_OK;

@@ -33,7 +33,7 @@ struct Res {
 	size_t conv1, conv2, tw, tb, res;   // offsets in the buckets (res = SIZE_MAX when cin == cout)
 	bla_resnet_ws ws;
 	float* result;
-	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
+	ResnetPads pads = {nullptr, nullptr, false, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // batched: zero-haloed padded copies of the two convolution inputs, filled by the norm kernels
 	float* dtb = nullptr;                 // batched: per-image channel sums of the time-projection gradient [B][cout], kept until the pass's last launch
 	size_t drop_off;                      // offset of this block's dropout decisions in the caller's mask
 };
@@ -73,6 +73,10 @@ struct bla_unet {
 	float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *gskip[4] = {nullptr, nullptr, nullptr, nullptr};
 	TimeJob* time_jobs = nullptr;                // device, one per ResNet block (batch > 1)
 	float* g_res = nullptr;                                      // batched: the residual 1x1 convolutions' data gradient (largest block input)
+	// batched, weight gradients on the context's side lane (BLA_UNET_SIDE=0: off): every gradient buffer of a backward pass is written ONCE (a pool instead of
+	// three rotating buffers), every block has its own g_out_b -- what the lane reads stays intact until the pass's one join
+	bool side = false;
+	std::vector<float*> gpool;
 	float* dy_pad[4] = {nullptr, nullptr, nullptr, nullptr};   // per resolution: padded gradient scratch of the blocks' first convolutions (halo zeroed once)
 	KernelPrepJob *prep_fwd = nullptr, *prep_bwd = nullptr;   // device: every convolution's kernel matrix re-ordered / flipped in ONE launch per pass
 	int n_prep_fwd = 0, n_prep_bwd = 0;
@@ -354,6 +358,12 @@ bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, i
 	    (st = dalloc(m, &m->out_sd, g0)))
 		return fail(st);
 	max_flip = std::max(max_flip, (size_t)cfg->in_channels * D[0] * cfg->kernel * cfg->kernel);
+	static const bool side_on = [] { const char* e = getenv("BLA_UNET_SIDE"); return !(e && e[0] == '0'); }();
+	m->side = side_on && batch > 1;
+	if (m->side) {
+		for (int i = 0; i < 48; i++) { float* q; if ((st = dalloc(m, &q, max_act))) return fail(st); m->gpool.push_back(q); }
+		for (Res& r : m->res) if ((st = dalloc(m, &r.pads.g_out_b, (size_t)r.cout * r.h * r.w * B))) return fail(st);
+	}
 	if ((st = dalloc(m, &m->t1, max_act)) || (st = dalloc(m, &m->t2, max_act)) || (st = dalloc(m, &m->t3, max_act)) || (st = dalloc(m, &m->sc.g_out_a, max_cout_hw)) ||
 	    (st = dalloc(m, &m->sc.g_out_b, max_cout_hw)) || (st = dalloc(m, &m->sc.g_in, max_cin_hw)) || (st = dalloc(m, &m->sc.flip, max_flip)) ||
 	    (st = alloc_att_ws(m, m->agrad, max_s, cfg->key_dim)) || (st = dalloc(m, &m->dtb, B * max_cout)) || (st = dalloc(m, &m->partials, B * max_cd)))
@@ -542,7 +552,7 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		bla_resnet_params p = {P + r.conv1, P + r.conv2, P + r.tw, P + r.tb, r.res != kNone ? P + r.res : nullptr};
 		bla_resnet_grads gr = {G + r.conv1, G + r.conv2, G + r.tw, G + r.tb, r.res != kNone ? G + r.res : nullptr};
 		return resnet_backward_batched(stream, B, g, x, temb, &p, &r.ws, &gr, &m->sc, B > 1 ? r.dtb : m->dtb, out, r.h, r.w, r.cin, r.cout, c.kernel, c.time_dim,
-		                               c.group_size, B > 1 && m->time_jobs ? RESNET_DEFER_TIME_GRADS : 0, B > 1 ? &r.pads : nullptr);
+		                               c.group_size, (B > 1 && m->time_jobs ? RESNET_DEFER_TIME_GRADS : 0) | (m->side ? RESNET_WGRAD_SIDE : 0), B > 1 ? &r.pads : nullptr);
 	};
 	auto att = [&](int i, const float* g, const float* x, float* out) -> bla_status {
 		Att& a = m->att[i];
@@ -550,6 +560,15 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		                                          G + a.wo, out, a.c, a.h * a.w, c.key_dim, 0);
 	};
 	auto conv = [&](Conv& k, const float* g, const float* x, float* out) -> bla_status {
+		if (m->side) {      // weight gradient on the side lane (g and x stay intact until the join below), data gradient here
+			hipStream_t lane;
+			bla_status s2 = side_lane_fork(s, &lane);
+			if (s2) return s2;
+			s2 = conv2d_backward_batched(lane, g, x, P + k.kern, G + k.kern, nullptr, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride, nullptr, nullptr);
+			side_lane_done();
+			if (s2) return s2;
+			return conv2d_backward_batched(stream, g, x, P + k.kern, nullptr, out, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride, nullptr, k.prep_bwd);
+		}
 		return conv2d_backward_batched(stream, g, x, P + k.kern, G + k.kern, out, m->sc.flip, B, k.h, k.w, k.k, k.cin, k.cout, k.stride, nullptr, k.prep_bwd);
 	};
 	if (m->n_prep_bwd) { st = conv_prepare_kernels(stream, m->prep_bwd, m->n_prep_bwd, m->prep_max); if (st) return st; }
@@ -569,54 +588,58 @@ bla_status bla_unet_backward_f32(bla_unet* m, void* stream, const float* d_noise
 		BLA_HIP(hipGetLastError());
 		return BLA_OK;
 	};
-	// three rotating gradient buffers: a block never writes the buffer it reads
+	// three rotating gradient buffers: a block never writes the buffer it reads.  With the weight gradients on the side lane every WRITE takes a fresh buffer
+	// from the pool instead (F(x) below), so what the lane still reads -- the gradient a block or convolution came in with -- is never overwritten in this pass
 	float *a = m->t1, *b = m->t2, *cbuf = m->t3;
+	size_t gp = 0;
+	auto F = [&](float*& p) -> float* { if (m->side) p = m->gpool[gp++ % m->gpool.size()]; return p; };
 	const size_t hw0 = (size_t)H[0] * W[0];
 	const size_t n0 = (size_t)D[0] * hw0, n1 = (size_t)D[1] * H[1] * W[1], n2 = (size_t)D[2] * H[2] * W[2], n3 = (size_t)D[3] * H[3] * W[3];
 	const int nout = (int)(c.in_channels * hw0 * B);
-	hipLaunchKernelGGL(unet_loss_grad_kernel, dim3(grid_of((size_t)nout)), dim3(256), 0, s, m->outc.out, d_noise, a, nout);   // :1353-1364
+	hipLaunchKernelGGL(unet_loss_grad_kernel, dim3(grid_of((size_t)nout)), dim3(256), 0, s, m->outc.out, d_noise, F(a), nout);   // :1353-1364
 	BLA_HIP(hipGetLastError());
 	// output processing, :1367-1369: convolution, ReLU gate, group norm
-	TRY(conv(m->outc, a, m->out_relu, b));
-	TRY(bla_group_norm_ddx_gated_batched_f32(stream, B, b, a, m->res[17].result, m->out_mu, m->out_sd, D[0], c.group_size, (int)hw0, m->out_relu, nullptr));
+	TRY(conv(m->outc, a, m->out_relu, F(b)));
+	TRY(bla_group_norm_ddx_gated_batched_f32(stream, B, b, F(a), m->res[17].result, m->out_mu, m->out_sd, D[0], c.group_size, (int)hw0, m->out_relu, nullptr));
 	// fourth up-sampling stage, :1372-1374
-	TRY(res(17, a, m->res[16].result, b)); TRY(res(16, b, m->cat[3], a));
-	TRY(split(3, a, b, n0));
+	TRY(res(17, a, m->res[16].result, F(b))); TRY(res(16, b, m->cat[3], F(a)));
+	TRY(split(3, a, F(b), n0));
 	// third, :1377-1383 (resize and the optional convolution, then attention 2, ResNet 2, attention 1, ResNet 1)
-	TRY(upsample(2, b, a, cbuf));
-	TRY(att(4, cbuf, m->res[15].result, a)); TRY(res(15, a, m->att[3].out, b)); TRY(att(3, b, m->res[14].result, a)); TRY(res(14, a, m->cat[2], b));
-	TRY(split(2, b, a, n1));
+	TRY(upsample(2, b, F(a), F(cbuf)));
+	TRY(att(4, cbuf, m->res[15].result, F(a))); TRY(res(15, a, m->att[3].out, F(b))); TRY(att(3, b, m->res[14].result, F(a))); TRY(res(14, a, m->cat[2], F(b)));
+	TRY(split(2, b, F(a), n1));
 	// second, :1386-1390
-	TRY(upsample(1, a, b, cbuf));
-	TRY(res(13, cbuf, m->res[12].result, a)); TRY(res(12, a, m->cat[1], b));
-	TRY(split(1, b, a, n2));
+	TRY(upsample(1, a, F(b), F(cbuf)));
+	TRY(res(13, cbuf, m->res[12].result, F(a))); TRY(res(12, a, m->cat[1], F(b)));
+	TRY(split(1, b, F(a), n2));
 	// first, :1393-1397
-	TRY(upsample(0, a, b, cbuf));
-	TRY(res(11, cbuf, m->res[10].result, a)); TRY(res(10, a, m->cat[0], b));
-	TRY(split(0, b, a, n3));
+	TRY(upsample(0, a, F(b), F(cbuf)));
+	TRY(res(11, cbuf, m->res[10].result, F(a))); TRY(res(10, a, m->cat[0], F(b)));
+	TRY(split(0, b, F(a), n3));
 	// middle, :1400-1402
-	TRY(res(9, a, m->att[2].out, b)); TRY(att(2, b, m->res[8].result, a)); TRY(res(8, a, m->res[7].result, b));
+	TRY(res(9, a, m->att[2].out, F(b))); TRY(att(2, b, m->res[8].result, F(a))); TRY(res(8, a, m->res[7].result, F(b)));
 	// fourth down-sampling stage, :1405-1409: the skip's gradient joins the main path's
 	TRY(bla_add_f32(stream, b, m->gskip[0], n3 * B));
-	TRY(res(7, b, m->res[6].result, a)); TRY(res(6, a, m->down[2].out, b));
+	TRY(res(7, b, m->res[6].result, F(a))); TRY(res(6, a, m->down[2].out, F(b)));
 	// third, :1412-1417
-	TRY(conv(m->down[2], b, m->res[5].result, a));
+	TRY(conv(m->down[2], b, m->res[5].result, F(a)));
 	TRY(bla_add_f32(stream, a, m->gskip[1], n2 * B));
-	TRY(res(5, a, m->res[4].result, b)); TRY(res(4, b, m->down[1].out, a));
+	TRY(res(5, a, m->res[4].result, F(b))); TRY(res(4, b, m->down[1].out, F(a)));
 	// second, :1420-1427
-	TRY(conv(m->down[1], a, m->att[1].out, b));
-	TRY(att(1, b, m->res[3].result, a));
+	TRY(conv(m->down[1], a, m->att[1].out, F(b)));
+	TRY(att(1, b, m->res[3].result, F(a)));
 	TRY(bla_add_f32(stream, a, m->gskip[2], n1 * B));
-	TRY(res(3, a, m->att[0].out, b)); TRY(att(0, b, m->res[2].result, a)); TRY(res(2, a, m->down[0].out, b));
+	TRY(res(3, a, m->att[0].out, F(b))); TRY(att(0, b, m->res[2].result, F(a))); TRY(res(2, a, m->down[0].out, F(b)));
 	// first, :1430-1435
-	TRY(conv(m->down[0], b, m->res[1].result, a));
+	TRY(conv(m->down[0], b, m->res[1].result, F(a)));
 	TRY(bla_add_f32(stream, a, m->gskip[3], n0 * B));
-	TRY(res(1, a, m->res[0].result, b));
+	TRY(res(1, a, m->res[0].result, F(b)));
 	TRY(res(0, b, m->last_x, nullptr));   // nothing consumes the gradient of the image: the first block forms its weight gradients only
 	if (B > 1 && m->time_jobs) {   // the 18 blocks' time-weight / time-bias gradients from the channel sums each block left behind (:1191-1199)
 		hipLaunchKernelGGL(time_grads_all_kernel, dim3(18, (unsigned)((c.time_dim + 7) / 8)), dim3(256), 0, s, m->time_jobs, temb, B, c.time_dim);
 		BLA_HIP(hipGetLastError());
 	}
+	if (m->side) TRY(side_lane_join(s));      // the weight gradients are in when this stream moves on
 	return BLA_OK;
 }
 #undef TRY
