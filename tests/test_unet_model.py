@@ -292,3 +292,37 @@ def test_reference_constants_against_the_oracle(pkg, ora):
             worst = (name, e / d32, e)
         assert e <= d32, f"{name}: {e:.3e} from the fp64 oracle, the fp32 reference {d32:.3e}"
     print(f"worst gradient tensor relative to the fp32 reference's own distance: {worst[0]} {worst[2]:.2e} = {worst[1]:.2f} x")
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_batched_passes_are_bit_reproducible(pkg, B):
+    """The batched backward pass issues its weight gradients on a second stream (the context's side lane: one-directional forks, one join per pass) and takes every
+    gradient buffer from a write-once pool.  If the lane ever read a buffer the main stream had moved on to overwrite, or the join came too early, the gradient
+    bucket would differ between passes: eight back-to-back forward + backward passes at the reference's constants (batch 8 and 64), no host synchronisation between them,
+    must leave bit-identical buckets and predictions -- and so must a pass issued after a synchronisation."""
+    pkg.init(0)
+    L = pkg.lib(); chk = pkg.native.check
+    cfg = dict(image_h=32, image_w=32, in_channels=3, dims=[128, 256, 256, 256], time_dim=512, kernel=3, group_size=32, key_dim=16)
+    h, tensors = build(pkg, cfg, B)
+    _, total = load_params(pkg, h, tensors, cfg)
+    x = pkg.to_device(uniform(7931, (B, 3, 32, 32), -1, 1, np.float32)); temb = pkg.to_device(uniform(7932, (B, 512), -1, 1, np.float32))
+    noise = pkg.to_device(uniform(7933, (B, 3, 32, 32), -1, 1, np.float32))
+    snaps = [pkg.empty((total,)) for _ in range(3)]
+    outs = [pkg.empty((B, 3, 32, 32)) for _ in range(3)]
+
+    def one_pass(slot):
+        chk(L.bla_unet_forward_f32(h, None, x.ptr, temb.ptr, None)); chk(L.bla_unet_backward_f32(h, None, noise.ptr))
+        if slot is not None:      # device-to-device on the same stream: ordered behind the pass, no host wait
+            chk(L.bla_memcpy_d2d(snaps[slot].ptr, L.bla_unet_grads(h), total * 4, None)); chk(L.bla_memcpy_d2d(outs[slot].ptr, L.bla_unet_output(h), B * 3 * 32 * 32 * 4, None))
+    one_pass(0)
+    for _ in range(6):
+        one_pass(None)
+    one_pass(1)
+    pkg.sync()
+    one_pass(2)
+    pkg.sync()
+    g = [sn.numpy() for sn in snaps]; o = [t.numpy() for t in outs]
+    assert np.isfinite(g[0]).all() and np.abs(g[0]).max() > 0
+    assert np.array_equal(g[0], g[1]) and np.array_equal(g[0], g[2]) and np.array_equal(o[0], o[1]) and np.array_equal(o[0], o[2])
+    chk(L.bla_unet_destroy(h))
+
