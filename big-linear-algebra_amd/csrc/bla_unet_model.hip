@@ -359,7 +359,7 @@ bla_status bla_unet_create_batched(bla_unet** out, const bla_unet_config* cfg, i
 		return fail(st);
 	max_flip = std::max(max_flip, (size_t)cfg->in_channels * D[0] * cfg->kernel * cfg->kernel);
 	static const bool side_on = [] { const char* e = getenv("BLA_UNET_SIDE"); return !(e && e[0] == '0'); }();
-	m->side = side_on && batch > 1;
+	m->side = side_on && batch > 1 && 48 * max_act * sizeof(float) <= ((size_t)16 << 30);   // (the write-once pool: at most 16 GiB of it -- beyond that, one stream and three rotating buffers)
 	if (m->side) {
 		for (int i = 0; i < 48; i++) { float* q; if ((st = dalloc(m, &q, max_act))) return fail(st); m->gpool.push_back(q); }
 		for (Res& r : m->res) if ((st = dalloc(m, &r.pads.g_out_b, (size_t)r.cout * r.h * r.w * B))) return fail(st);
