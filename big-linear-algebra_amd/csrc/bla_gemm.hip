@@ -741,17 +741,20 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 			// costs its area over the tile's in-loop efficiency (128x128 1.0, 128x64 0.95, 64x64 0.87), and a CU left with fewer than two
 			// workgroups loses the overlap between them (x 0.88).  Reproduces the measured order at 1024^3 (64x64: 87 vs 69 / 58 TFLOP/s),
 			// 2048^3 (128x64: 136 vs 124 / 123), 3072^3 (64x64: 125 vs 118 / 104 -- 576 big tiles are 2.25 rounds) and 4096^3 (128x128).
-			const int cand[8] = {3, 7, 4, 11, 13, 14, kCfgHs192, 18};
-			const double eff[8] = {1.0, 0.95, 0.87, 1.03, 1.03, 1.0, 1.03, 0.93};
+			// (128-row products with a long N -- the staged convolution's im2col product, 128 x 65536 x 1152 -- run 8-10 % faster on the half-slab 128 x 128 tile
+			// than on config 3 and another 1-2 % on 128 x 256: 168.6 / 154.9 / 153.3 us, tools/gemm_rect_probe.py; hence 14 a hair above 3 and 15 in the list)
+			const int cand[9] = {3, 7, 4, 11, 13, 14, kCfgHs192, 18, 15};
+			const double eff[9] = {1.0, 0.95, 0.87, 1.03, 1.03, 1.005, 1.03, 0.93, 1.02};
 			// Half-slab pipeline (configs 11, 13, 14, 17): one workgroup per CU by design (no x 0.88), whole tiles, plain epilogue, 16-byte aligned C
 			// only.  The tile is picked so that the tile count is a whole number of rounds over the CUs: 4096^2 = 256 tiles of 256x256, 3072^2 = 256
 			// of 192x192 (147.6 TFLOP/s against 128 on 64x64 tiles), 2048^2 = 256 of 128x128 (134.6 against 125.7 on 128x64).
 			const bool big_ok = k >= 32 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && !a.bias_row && !a.bias_col &&
 			                    !a.pre_act && a.act == BLA_ACT_NONE && !a.relu_mask && a.beta == 0.f && !a.row_sum_a;
 			double best = 0;
-			for (int i = 0; i < 8; i++) {
+			for (int i = 0; i < 9; i++) {
 				const Config& cc = kConfigs[cand[i]];
-				if (i >= 3 && i < 7 && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;
+				const bool hs_tile = (i >= 3 && i < 7) || i == 8;
+				if (hs_tile && !(big_ok && m % cc.bm == 0 && n % cc.bn == 0)) continue;
 				long t = (long)((m + cc.bm - 1) / cc.bm) * ((n + cc.bn - 1) / cc.bn);
 				// 64x64 tiles with two wave groups along K (config 18): the small problems where a CU holds one or two tiles (1024^3: 19.8 against 20.6 us,
 				// 1280^3: 41.9 against 45.3, 1536^3: 71 against 77); needs whole 32-deep slabs
@@ -760,7 +763,7 @@ static bla_status gemm_impl(void* stream, int transa, int transb, int m, int n, 
 				double cost = (double)rounds * cc.bm * cc.bn / eff[i];
 				if (t < 2L * cus && (i < 3 || i == 7)) cost /= 0.88;
 				if (t < cus && i < 3) cost *= 1.25;   // ... and will have its K cut over workgroups: slabs and a fold launch (1280^3 on 128x64 tiles: 51 us)
-				if (i >= 3 && i < 7 && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
+				if (hs_tile && t < cus) cost *= 2;   // a partly filled chip: leave it to the smaller tiles / split-K
 				if (i == 0 || cost < best) { best = cost; cfg = cand[i]; }
 			}
 		}
