@@ -61,6 +61,12 @@ __global__ void __launch_bounds__(256) gather_fold_epilogue_kernel(const float4*
 		if (out2) { const float4 a = add[i]; out2[i] = make_float4(s.x + a.x, s.y + a.y, s.z + a.z, s.w + a.w); }
 	}
 }
+// LDS of the image-window kernel (mode 7): two A slabs, two channel groups of the window -- [16 planes][128 / W + 2 rows][4 zeros + W], a group rounded up to
+// whole 1-KiB DMA instructions -- and 16 bytes of slack at either end (the kernel's W7_* constants)
+static size_t window_lds_bytes(int W) {
+	const size_t plane = (size_t)(128 / W + 2) * (W + 4), group = (16 * plane + 255) / 256 * 256;
+	return (2 * 128 * 16 + 2 * group + 8) * sizeof(float);
+}
 int gather_gemm_splits(int mode, int batch, int M, int N, int HWo) {
 	if (mode != 2 && mode != 4) return 1;
 	const long K = (long)batch * HWo;
@@ -108,8 +114,7 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 		a.tiles_m = M / 128; a.tiles_n = N / 128; a.k_per_split = K; a.splits = 1;
 		if (ep) { a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2; }
 		const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
-		const size_t plane = (size_t)(128 / W + 2) * W;
-		const size_t lds_bytes = (2 * 128 * 16 + 2 * 16 * plane + 8) * sizeof(float);
+		const size_t lds_bytes = window_lds_bytes(W);
 		if (W == 32) hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 7, false, true, 1, 32>), grid, block, lds_bytes, s, a);
 		else hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 16, 2, 2, true, false, 1, 2, false, 7, false, true, 1, 16>), grid, block, lds_bytes, s, a);
 		BLA_HIP(hipGetLastError());
@@ -192,8 +197,7 @@ static bla_status gather_plan(int mode, int batch, int M, int N, int K, const fl
 		            (uintptr_t)A % 16 == 0 && (long)batch * img_stride < (1L << 29) && (long)N * M < (1L << 31), BLA_ERR_INVALID, "mode 7 shape (M=%d N=%d K=%d H=%d W=%d C=%d)", M, N, K, H, W, ch);
 		a.A = A; a.lda = lda; a.k_per_split = K; a.splits = 1;
 		if (ep) { a.g_bias = ep->bias; a.g_bias_stride = ep->bias_stride; a.g_add = ep->add; a.g_out2 = ep->out2; }
-		const size_t plane = (size_t)(128 / W + 2) * W;
-		out->lds = (2 * 128 * 16 + 2 * 16 * plane + 8) * sizeof(float);
+		out->lds = window_lds_bytes(W);
 		out->grid = dim3((unsigned)(a.tiles_m * a.tiles_n), 1, 1);
 		out->gw = W;
 	} else {

@@ -90,13 +90,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   RC operand: image [BK][rows], read with ds_read_b32 of 32 consecutive floats -- no swizzle.
 // Needs K % BK == 0, 16-byte aligned rows and contiguous extents that are multiples of 4; rows /
 // columns past M / N are fetched from clamped addresses (their products are never stored).
-// mode 7: 16-byte chunk q of a channel group's image window ([16 planes][PL / GW rows][GW]) -> element offset in the image batch (channel group 0),
-// -1 when its image row does not exist (the chunk is then fetched from the zero words)
+// mode 7: 16-byte chunk q of a channel group's image window ([16 planes][rows][4 zeros + GW]) -> element offset in the image batch (channel group 0),
+// -1 when it is a row's leading zero chunk, when its image row does not exist, or when it lies in the tail that rounds a group up to whole DMA instructions
+// (the chunk is then fetched from the zero words).  The zero chunk in front of every row is both the column left of that row and the column right of the row
+// before it: the taps dx = -1 / +1 of a row's first / last pixel read a zero from LDS, and the fragments need no masking (one v_cndmask per MFMA before).
 template <int PL, int GW>
 __device__ __forceinline__ int window_chunk_offset(int q, int i0, int img_h, int img_hw, int img_base) {
-	const int plane = q / (PL / 4), r = q - plane * (PL / 4), wrow = r / (GW / 4), c4 = r - wrow * (GW / 4);
+	constexpr int CPR = GW / 4 + 1;
+	const int plane = q / (PL / 4), r = q - plane * (PL / 4), wrow = r / CPR, c4 = r - wrow * CPR;
 	const int row = i0 - 1 + wrow;
-	return (unsigned)row < (unsigned)img_h ? img_base + plane * img_hw + row * GW + c4 * 4 : -1;
+	return (plane < 16 && c4 > 0 && (unsigned)row < (unsigned)img_h) ? img_base + plane * img_hw + row * GW + (c4 - 1) * 4 : -1;
 }
 
 template <int ROWS, int BK>
@@ -130,9 +133,10 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 	constexpr bool G7 = GATHER == 7;
 	constexpr int GWS = GW ? GW : 32;   // (a valid divisor in the instantiations that have no image width)
 	constexpr int A_SZ = BM * BK, B_SZ = G7 ? 0 : BN * BK, KK = BK / 8, KKW = KK / WK;   // KKW: k-parts of a slab this wave multiplies
-	// mode 7: the image window in LDS behind the two A slab buffers -- [2 groups][16 planes][W7_RH rows][GW] floats, 16 bytes of slack before and after
-	constexpr int W7_RH = G7 ? 128 / GWS + 2 : 1, W7_PL = W7_RH * GWS, W7_GRP = 16 * W7_PL, W7_NI = W7_GRP / 256, W7_PW = (W7_NI + 3) / 4;
-	static_assert(!G7 || W7_GRP % 256 == 0, "a group is a whole number of 1-KiB DMA instructions");
+	// mode 7: the image window in LDS behind the two A slab buffers -- [2 groups][16 planes][W7_RH rows][4 zeros + GW] floats (a group rounded up to whole
+	// 1-KiB DMA instructions, the tail zeros too), 16 bytes of slack before and after
+	constexpr int W7_RH = G7 ? 128 / GWS + 2 : 1, W7_PITCH = GWS + 4, W7_PL = W7_RH * W7_PITCH, W7_GRP = (16 * W7_PL + 255) / 256 * 256, W7_NI = W7_GRP / 256, W7_PW = (W7_NI + 3) / 4;
+	static_assert(!G7 || (W7_GRP > 16 * W7_PL && W7_PW <= 9), "the float behind a group's last row is a zero of its own tail; the next group's window arrives within the nine slabs of a group");
 	static_assert(WK == 1 || (KK % WK == 0 && NBUF == 2 && !PERSIST && GATHER == 0 && !HS && !(TM == 4 && TN == 4)), "waves along K: the plain two-buffer pipeline only");
 	typedef KcImage<BM, BK> AI;
 	typedef KcImage<BN, BK> BI;
@@ -245,13 +249,10 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 	// tap, hipcc turns the pick into a scratch array, and with it the whole argument block: 720 bytes of scratch per lane, seen in the ISA)
 	int w7_i0 = 0, w7_base = 0;
 	unsigned w7_lane = 0;
-	bool w7_left = false, w7_right = false;
 	if (G7) {
 		const int b = n0 / p.g_HWo, i0 = (n0 - b * p.g_HWo) / GWS;    // the tile: rows i0 .. i0 + 128 / GW - 1 of image b
 		w7_i0 = i0; w7_base = b * p.g_img_stride;
-		w7_lane = (unsigned)((4 * h * W7_PL + wn0 + l31) * 4);
-		const int col = (wn0 + l31) % GWS;
-		w7_left = col == 0; w7_right = col == GWS - 1;
+		w7_lane = (unsigned)((4 * h * W7_PL + ((wn0 + l31) / GWS) * W7_PITCH + 4 + (wn0 + l31) % GWS) * 4);
 	}
 	if (GATHER == 1 || GATHER == 2) {
 #pragma unroll
@@ -754,7 +755,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 		unsigned w7_ad[2] = {0, 0}, w7_cur = 0;   // w7_cur: the A buffer offset of slab t (read_unit is told a slab by its A buffer)
 		auto w7_addr = [&](int g, int tap) -> unsigned {   // tap (p, q): window row r + p, column x + q - 1
 			const int pq = tap / 3;
-			return lds0 + (unsigned)((2 * A_SZ + 4 + (g & 1) * W7_GRP + pq * GWS + (tap - 3 * pq) - 1) * 4) + w7_lane;
+			return lds0 + (unsigned)((2 * A_SZ + 4 + (g & 1) * W7_GRP + pq * W7_PITCH + (tap - 3 * pq) - 1) * 4) + w7_lane;
 		};
 		constexpr int NM = 4 * TM * TN;                                       // MFMAs per k-part
 		auto opa = [&](const Frag& f, int im, int j) -> float { return AKC ? f.ka[im][j] : TM == 3 ? f.sa[j][im] : f.ra[j][im]; };
@@ -778,7 +779,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 				// `buf` is not a slab buffer here but which of the two slabs in flight (0: t, BUF_BYTES: t + 1)
 				const int x = u - UA, j = x / TN, b = x % TN;
 				const unsigned ad = buf == w7_cur ? w7_ad[0] : w7_ad[1];
-				asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sb[j][b]) : "v"(ad), "n"(((kk * 8 + j) * W7_PL + b * 32) * 4));
+				asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.sb[j][b]) : "v"(ad), "n"(((kk * 8 + j) * W7_PL + b * (32 / GWS) * W7_PITCH) * 4));
 			} else {
 				const int x = u - UA;
 				const unsigned ad = buf + b_ad[kk];
@@ -806,16 +807,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 				else asm volatile("" : "+v"(f.rb[x]));
 			}
 		};
-		auto w7_mask = [&](Frag& f) {   // mode 7: a lane on a row's first / last column gets its out-of-row tap (dx = -1 / +1) as a zero
-			if constexpr (G7) {
-				const int dx = w7_tap % 3 - 1;
-				const bool m = (dx < 0 && w7_left) || (dx > 0 && w7_right);
-#pragma unroll
-				for (int j = 0; j < 4; j++)
-#pragma unroll
-					for (int b = 0; b < TN; b++) f.sb[j][b] = m ? 0.f : f.sb[j][b];
-			}
-		};
 		// slab t in buffer t&1.  One uniform body for every slab: past the end the fetch cursor stays on the last slab (re-fetched
 		// into a buffer nobody reads again) and the "next" fragments are stale LDS that is never multiplied -- so there is no tail
 		// code, no branch in the loop, and the 256 accumulators never leave their registers.
@@ -838,7 +829,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 				Frag& use = (q & 1) ? Q : P;
 				Frag& fill = (q & 1) ? P : Q;
 				land(use);
-				w7_mask(use);
 				// dense: the read units spread evenly over the phase.  Convolution modes (16 MFMAs per phase): one unit per MFMA from the start and the
 				// rest of the MFMAs behind them -- spread evenly, the last unit is issued some 100 cycles before land() waits for it, less than an LDS round trip
 				constexpr int FRONT = (GATHER != 0 && NU <= NM) ? 1 : 0;
@@ -853,7 +843,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 			}
 			// last phase (k-part KK-1 from Q): slab t+1 has landed for everyone, and everyone is done reading slab t
 			land(Q);
-			w7_mask(Q);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 			// The gather-table entries for the DMAs below were loaded a slab ago and have landed with everything else (vmcnt(0) above) -- but hipcc does not
@@ -906,7 +895,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 			// the one stop of the slab: this slab's fragments are in registers, slab t + 1 has landed for every wave, nobody needs slab t's LDS any more
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-			for (int kk = 0; kk < KK; kk++) { land(use[kk]); w7_mask(use[kk]); }
+			for (int kk = 0; kk < KK; kk++) land(use[kk]);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 #if defined(__HIP_DEVICE_COMPILE__)
