@@ -1015,7 +1015,7 @@ static bla_status launch_implicit(hipStream_t s, ConvArgs& a, int batch = 1, siz
 				BLA_HIP(hipGetLastError());
 				padded = mine;
 			}
-			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, pg.hh, pg.wh, a.K, (int)(a.g.c * pg.plane_floats));
+			return gather_gemm(s, 4, batch, a.N, a.M, a.K * batch, a.A, a.lda, a.out, a.ldo, padded, pix, taps, pg.hh, pg.wh, a.K, (int)(a.g.c * pg.plane_floats), nullptr, a.g.wo);
 		}
 		// weight gradient: columns = taps, contraction over (image, output pixel); A = del_y [image][M][HWo]
 		return gather_gemm(s, 2, batch, a.M, a.N, a.K * batch, a.A, a.lda, a.out, a.ldo, a.img, ptab, a.tab, a.g.h, a.g.w, a.K, (int)img_stride);
@@ -1533,14 +1533,14 @@ static bla_status conv2d_backward(void* stream, const float* d_del_y, const floa
 		ad.padded_src = k % 2 == 1 ? dy_padded : nullptr;
 		const FwdPath dpath = plan_forward(ad, batch).path;
 		static const long pair_max_cols = [] { const char* e = getenv("BLA_CONV_PAIR_COLS"); return e && *e ? atol(e) : 2048L; }();
-		if (pair_on && (long)ad.N * batch <= pair_max_cols && use_tiled_gather(aw, batch, 2) && fits_w && aw.g.wo % 4 == 0 && aw.N % 4 == 0 && gather_pair_fits(4, aw.N, aw.M) &&
+		if (pair_on && (long)ad.N * batch <= pair_max_cols && use_tiled_gather(aw, batch, 2) && fits_w && (aw.g.wo == 4 || aw.g.wo == 8 || aw.g.wo % 16 == 0) && aw.N % 4 == 0 && gather_pair_fits(4, aw.N, aw.M) &&
 		    (dpath == FWD_TILED_WINDOW || (dpath == FWD_TILED_PADDED && gather_pair_fits(3, ad.M, ad.N * batch)))) {
 			const int2 *taps_w, *pix_w, *taps_d = nullptr, *pix_d = nullptr;
 			st = get_padded_tables(s, aw.g, &taps_w, &pix_w);
 			if (st) return st;
 			if (dpath == FWD_TILED_PADDED) { st = get_padded_tables(s, ad.g, &taps_d, &pix_d); if (st) return st; }
 			// the two products as gather_gemm would take them (launch_implicit's weight-gradient and forward branches)
-			GatherProduct gw = {4, aw.N, aw.M, aw.K * batch, aw.A, aw.lda, aw.out, aw.ldo, nullptr, pix_w, taps_w, pgw.hh, pgw.wh, aw.K, (int)(aw.g.c * pgw.plane_floats), GatherEpilogue{}};
+			GatherProduct gw = {4, aw.N, aw.M, aw.K * batch, aw.A, aw.lda, aw.out, aw.ldo, nullptr, pix_w, taps_w, pgw.hh, pgw.wh, aw.K, (int)(aw.g.c * pgw.plane_floats), GatherEpilogue{}, aw.g.wo};
 			GatherProduct gd = dpath == FWD_TILED_WINDOW
 				? GatherProduct{7, ad.M, ad.N * batch, ad.K, nullptr, ad.K, ad.out, ad.ldo, ad.img, nullptr, nullptr, ad.g.h, ad.g.w, ad.N, (int)y_sz, GatherEpilogue{}}
 				: GatherProduct{3, ad.M, ad.N * batch, ad.K, nullptr, ad.lda, ad.out, ad.ldo, nullptr, taps_d, pix_d, pgd.hh, pgd.wh, ad.N, (int)(ad.g.c * pgd.plane_floats), GatherEpilogue{}};

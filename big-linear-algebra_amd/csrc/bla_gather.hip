@@ -16,12 +16,18 @@ static bool gather_hs(int mode, int M, int N) {
 	static const bool hs4 = [] { const char* e = getenv("BLA_CONV_HS"); return !(e && e[0] == '1'); }();
 	return use_hs && M % 128 == 0 && N % 128 == 0 && (mode == 3 || (mode == 4 && hs4));
 }
+// mode 4 on the half-slab kernel: a slab's 16 output pixels must sit at the same places relative to its first pixel whatever the slab (bla_gemm_kernel.h)
+static bool gather4_fixed_offsets(int wo) { return wo == 4 || wo == 8 || (wo >= 16 && wo % 16 == 0); }
 static int gather_k_per_split(int mode, int batch, int M, int N, int HWo) {
 	const long K = (long)batch * HWo;
 	if (mode != 2 && mode != 4) return (int)K;
 	const int cus = ctx().num_cus > 0 ? ctx().num_cus : 256;
 	const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-	const long slots = 2L * cus;   // two workgroups per CU on either form
+	// two workgroups per CU on either form.  On the side lane (the U-Net's weight gradients beside the main chain's kernels) ONE: the half-slab weight-gradient
+	// kernel takes 108 registers, so one of its workgroups fits a CU BESIDE two of the main chain's gather kernels (188 / 172 registers each) and fills the matrix
+	// pipe's bubbles instead of taking one of their two places -- batch-64 backward 9.83 -> 9.33 ms, batch 128 18.7 -> 16.9 (BLA_LANE_SLOTS=2: the old split)
+	static const long lane_slots = [] { const char* e = getenv("BLA_LANE_SLOTS"); return e && *e ? atol(e) : 1L; }();
+	const long slots = (ctx().side_lane && mode == 4 ? lane_slots : 2L) * cus;
 	long splits = slots / tiles;
 	const long slabs = K / 16;
 	if (splits > slabs / 8) splits = slabs / 8;      // at least 8 slabs per split
@@ -100,7 +106,7 @@ bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const Gat
 }
 
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
-                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep) {
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep, int wo) {
 	BLA_REQUIRE((mode >= 1 && mode <= 4) || mode == 7, BLA_ERR_INVALID, "gather mode %d", mode);
 	if (mode == 7) {   // the image window in LDS (3x3, stride 1): whole 128-pixel tiles inside one image, one pass over K, A = kernels re-ordered [M][(group, tap, channel)]
 		const int ch = HWo > 0 ? img_stride / HWo : 0;
@@ -144,7 +150,8 @@ bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, 
 	dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits), block(256);
 	size_t lds_bytes = 2 * (128 + 128) * 16 * sizeof(float);
 	// whole tiles: the half-slab pipeline (fragment sets per k-half, every LDS read and DMA dealt out between MFMAs) -- BLA_CONV_HS=0 keeps the older form
-	const bool hs = gather_hs(mode, M, N);
+	const bool hs = gather_hs(mode, M, N) && (mode != 4 || gather4_fixed_offsets(wo));
+	a.g_wo = wo;
 	const bool with_ep = ep && (ep->bias || ep->out2);
 	if (with_ep) {
 		BLA_REQUIRE(mode == 3 && hs, BLA_ERR_INVALID, "the fused convolution epilogue needs the half-slab forward kernel (gather3_fuses_epilogue)");
@@ -251,7 +258,10 @@ static bla_status gather_pair(hipStream_t s, const GatherPlan& w, const GatherPl
 }
 
 static bla_status plan_of(const GatherProduct& g, int batch, GatherPlan* out) {
-	return gather_plan(g.mode, batch, g.M, g.N, g.K, g.A, g.lda, g.C, g.ldc, g.img, g.ktab, g.ntab, g.H, g.W, g.HWo, g.img_stride, &g.ep, out);
+	BLA_REQUIRE(g.mode != 4 || gather4_fixed_offsets(g.wo), BLA_ERR_INVALID, "gather pair: the weight gradient's map is %d pixels wide (4, 8 or a multiple of 16)", g.wo);
+	bla_status st = gather_plan(g.mode, batch, g.M, g.N, g.K, g.A, g.lda, g.C, g.ldc, g.img, g.ktab, g.ntab, g.H, g.W, g.HWo, g.img_stride, &g.ep, out);
+	if (!st) out->a.g_wo = g.wo;
+	return st;
 }
 size_t gather_product_slab_floats(const GatherProduct& g, int batch) {
 	if (g.mode == 7) return 0;

@@ -46,6 +46,7 @@ struct GemmArgs {
 	const float* g_img; const float* g_zero;
 	const int2* g_ktab; const int2* g_ntab;   // {element offset, y | x << 16} per tap / per output pixel
 	int g_mode, g_H, g_W, g_HWo, g_img_stride;
+	int g_wo;                                 // mode 4 on the half-slab pipeline: width of the output map (g_W is the padded copy's row pitch there)
 	// mode 3 on the half-slab pipeline, one pass over K: the adds the U-Net puts behind a convolution, applied where the tile is stored
 	// (out = product + g_bias[image * g_bias_stride + row]; g_out2 = out + g_add, same layout as out; each optional)
 	const float* g_bias; int g_bias_stride; const float* g_add; float* g_out2;
@@ -236,6 +237,21 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 #pragma unroll
 		for (int i = 0; i < B_NI; i++) gb[i] += (ptrdiff_t)g_img * p.N * p.g_HWo + (g_r - k_begin);   // B = del_y [image][N][HWo], ldb = HWo
 	}
+	// mode 4, half-slab pipeline: a slab is 16 consecutive output pixels starting at a multiple of 16, and the map is 4, 8 or a multiple of 16 pixels wide
+	// (the host checks), so where a lane's chunk of four pixels sits RELATIVE to the slab's first pixel in the padded copy never changes: the lane's byte
+	// offset (tap row + that place) is fixed for the whole K loop and goes into the buffer load's VGPR offset, the slab's first pixel (image, row, column:
+	// wave-uniform) into its SGPR offset -- no table load, no select and no 64-bit address per DMA instruction (before: four scalar loads per slab, three
+	// v_cndmask and a 64-bit add per instruction; the counters showed 0.7 VALU instructions per MFMA beside the MFMAs themselves).
+	int g4_voff[A_NI], g4_pix0 = 0, g4_col = 0, g4_soff = 0, g4_step = 0, g4_step_end = 0;
+	if (GATHER == 4 && HS) {
+		const int wo = p.g_wo, wh = p.g_W;
+#pragma unroll
+		for (int i = 0; i < A_NI; i++) g4_voff[i] = (g4_tap[i] + (g4_chunk[i] / wo) * wh + g4_chunk[i] % wo) * 4;
+		g4_col = g_r % wo; g4_pix0 = (g_r / wo) * wh + g4_col;
+		g4_step = wo >= 16 ? 16 : (16 / wo) * wh;                  // to the next slab inside a row / over whole rows
+		g4_step_end = wo >= 16 ? wh - wo + 16 : g4_step;            // from a row's last slab to the next row's first
+		g4_soff = (g_img * p.g_img_stride + g4_pix0) * 4;
+	}
 	int g3_base = 0;              // mode 3: padded-image offset of this lane's four columns
 	if (GATHER == 3) {
 		int n = min(n0 + (lane % G3_CPR) * 4, p.N - 4);
@@ -289,6 +305,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 	// raw descriptors, no bounds (rows / columns past the matrix are fetched from clamped offsets); lane offsets in bytes
 	__amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7fffffff, 0x00020000);
 	__amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7fffffff, 0x00020000);
+	__amdgpu_buffer_rsrc_t rsrc_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATHER == 4 ? p.g_img : p.A), 0, 0x7fffffff, 0x00020000);
 	int voff_a[A_NI], voff_b[B_NI], soff_a = 0, soff_b = 0;
 #pragma unroll
 	for (int i = 0; i < A_NI; i++) voff_a[i] = A_BUF ? (int)((ga[i] - p.A) * 4) : 0;
@@ -478,7 +495,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 	// Gather tables of the half-slab pipeline: the entries a slab's DMA instructions need are wave-uniform (tap rows of mode 3, the four
 	// pixel chunks of mode 4), so they are SCALAR loads, issued when the cursor moves -- a whole slab before the DMA that uses them.  (A per-lane
 	// table load in front of each DMA waits on vmcnt, i.e. for every LDS-DMA issued before it: 256->256 @16x16 ran 11 % slower that way.)
-	int hs_tap[B_NI][2], hs_pix[4] = {0, 0, 0, 0};
+	int hs_tap[B_NI][2];
 	auto hs_prefetch = [&]() {
 		if (GATHER == 3) {
 #pragma unroll
@@ -487,23 +504,15 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 				hs_tap[i][0] = p.g_ktab[row].x; hs_tap[i][1] = G3_RPI == 2 ? p.g_ktab[row + 1].x : 0;
 			}
 		}
-		if (GATHER == 4) {
-			const int r = __builtin_amdgcn_readfirstlane(g_r);
-#pragma unroll
-			for (int c = 0; c < 4; c++) hs_pix[c] = p.g_ktab[r + 4 * c].x;
-		}
 	};
-	if (HALFSLAB && (GATHER == 3 || GATHER == 4)) hs_prefetch();
+	if (HALFSLAB && GATHER == 3) hs_prefetch();
 
 	auto dma_one = [&](int buf, int d) {   // d-th DMA instruction of a slab; the offsets / gather cursors advance in dma_advance()
 		float* base = lds + buf * (A_SZ + B_SZ);
 		if (d < A_NI) {
 			const int i = d;
-			if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy)
-				const int c = g4_chunk[i] >> 2;     // which of the slab's four pixel chunks this lane fetches: its offset was loaded a slab ahead (hs_pix)
-				const int pix = c == 0 ? hs_pix[0] : c == 1 ? hs_pix[1] : c == 2 ? hs_pix[2] : hs_pix[3];
-				const float* src = p.g_img + (size_t)g_img * p.g_img_stride + (g4_tap[i] + pix);
-				__builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
+			if (GATHER == 4) {   // gathered operand: 16-byte chunk of four pixels of this lane's tap row (padded image copy): fixed lane offset + the slab's scalar offset
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_img, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, g4_voff[i], g4_soff, 0, 0);
 			} else if (A_BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, voff_a[i], soff_a, 0, 0);
 			else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + g_adv_a), (lds_ptr_t)(base + (wave * A_NI + i) * 256), 16, 0, 0);
 		} else if (G7) {
@@ -535,7 +544,11 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 			const bool wrap = r1 >= p.g_HWo;
 			soff_b += (really ? BK * 4 : 0) + (wrap ? (p.N - 1) * p.g_HWo * 4 : 0);
 			g_r = wrap ? 0 : r1; g_img += wrap ? 1 : 0;
-			hs_prefetch();
+			const int c1 = g4_col + 16;
+			const bool row_end = c1 >= p.g_wo;
+			g4_pix0 = wrap ? 0 : g4_pix0 + (really ? (row_end ? g4_step_end : g4_step) : 0);
+			g4_col = (wrap || row_end) ? 0 : (really ? c1 : g4_col);
+			g4_soff = __builtin_amdgcn_readfirstlane((g_img * p.g_img_stride + g4_pix0) * 4);
 			return;
 		}
 		if (A_BUF) soff_a += sa; else g_adv_a += really ? a_step : 0;
@@ -853,10 +866,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(GemmArgs p, const int blk_x, 
 			if constexpr (GATHER == 3) {
 #pragma unroll
 				for (int i = 0; i < B_NI; i++) { asm volatile("" : "+v"(hs_tap[i][0])); if (G3_RPI == 2) asm volatile("" : "+v"(hs_tap[i][1])); }
-			}
-			if constexpr (GATHER == 4) {
-#pragma unroll
-				for (int c = 0; c < 4; c++) asm volatile("" : "+v"(hs_pix[c]));
 			}
 #endif
 			constexpr int PER = 2 * (NU + NDMA) <= NM ? 2 : 1;   // MFMAs after each read unit / DMA instruction

@@ -60,7 +60,8 @@ int gather_gemm_splits(int mode, int batch, int M, int N, int HWo);   // K split
 struct GatherEpilogue { const float* bias; int bias_stride; const float* add; float* out2; };   // mode 3: out = product + bias[image * stride + row]; out2 = out + add
 bool gather3_fuses_epilogue(int M, int N, int K);                      // true: gather_gemm(mode 3, ...) takes a GatherEpilogue
 bla_status gather_gemm(hipStream_t s, int mode, int batch, int M, int N, int K, const float* A, int lda, float* C, int ldc, const float* img,
-                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep = nullptr);
+                       const int2* ktab, const int2* ntab, int H, int W, int HWo, int img_stride, const GatherEpilogue* ep = nullptr, int wo = 0);
+// (wo: mode 4 -- the output map's width; 4, 8 or a multiple of 16 puts the weight gradient on the half-slab kernel with fixed lane offsets, anything else (or 0) on the older form)
 // mode 3, up to four products over the same padded image in one launch (bla_gather.hip): each class its kernels A [M][K] (lda = K), tap table and output
 struct GatherClass { const float* A; int K; const int2* ktab; float* C; };
 bool gather_classes_fit(int ncls, int M, int N);
@@ -69,7 +70,7 @@ bla_status gather_gemm_classes(hipStream_t s, int batch, int M, int N, const Gat
 
 // Both gradients of one batched convolution in ONE launch (gather_pair_kernel, bla_gemm_kernel.h): w = the weight gradient as gather_gemm(mode 4, ...) takes it,
 // d = the data gradient as gather_gemm(mode 7 or 3, ...) takes it (whole 128 x 128 tiles: gather_pair_fits); slabs: gather_product_slab_floats floats each (0: none)
-struct GatherProduct { int mode, M, N, K; const float* A; int lda; float* C; int ldc; const float* img; const int2* ktab; const int2* ntab; int H, W, HWo, img_stride; GatherEpilogue ep; };
+struct GatherProduct { int mode, M, N, K; const float* A; int lda; float* C; int ldc; const float* img; const int2* ktab; const int2* ntab; int H, W, HWo, img_stride; GatherEpilogue ep; int wo; };   // wo: as gather_gemm's
 bool gather_pair_fits(int mode, int M, int N);
 size_t gather_product_slab_floats(const GatherProduct& g, int batch);
 bla_status gather_pair_products(hipStream_t s, int batch, const GatherProduct& w, float* w_slab, const GatherProduct& d, float* d_slab);
